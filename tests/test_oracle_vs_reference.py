@@ -1,0 +1,65 @@
+"""Side-by-side: the oracle and the REAL reference in one process, fresh seeds, exact equality demanded.
+Skipped wherever /root/reference is absent (always on the GPU box)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.ref_loader import reference_available
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not reference_available(), reason="/root/reference not present")]
+
+CASES = [
+    # sd, H, W, steps, R, vbs, seed, patch, tiled, controlnet
+    ("1.5", 512, 512, 3, 0, 1, 11, None, False, False),
+    ("1.5", 512, 1024, 3, 3, 4, 12, None, False, False),
+    ("1.5", 1024, 512, 2, 2, 3, 13, None, False, False),
+    ("1.5", 1080, 1920, 2, 2, 4, 14, None, False, False),
+    ("1.5", 768, 768, 2, 2, 4, 15, 48, False, False),
+    ("1.5", 640, 896, 2, 1, 4, 16, None, True, False),
+    ("XL1.0", 1024, 2048, 2, 2, 16, 17, None, False, False),
+    ("XL1.0", 1024, 1536, 2, 1, 2, 18, 96, False, False),
+    ("1.5", 512, 1024, 2, 2, 4, 19, None, False, True),
+    ("XL1.0", 1024, 2048, 2, 1, 16, 20, None, False, True),
+]
+
+
+@pytest.mark.parametrize("sd,H,W,steps,R,vbs,seed,patch,tiled,cn", CASES)
+def test_generate_image_bit_identical(sd, H, W, steps, R, vbs, seed, patch, tiled, cn):
+    from tests.golden.make_golden import build
+    from tests.golden import cases
+    from tests.test_oracle_golden import make_oracle
+
+    xl = sd.startswith("XL")
+    pipe, ref, _ = build(sd, 128 if xl else 64, vbs=vbs, controlnet=cn, patch=patch)
+    pipe.seed_everything(seed)
+    cap = {}
+    fn = "tiled_decode" if tiled else "decode_latents"
+    orig = getattr(pipe, fn)
+
+    def grab(z):
+        cap["z"] = z.clone()
+        cap["img"] = orig(z)
+        return cap["img"]
+
+    setattr(pipe, fn, grab)
+    kw = dict(cases.E2E_KW)
+    okw = dict(kw)
+    if cn:
+        ds = pipe.get_downsample_size(H, W)
+        cond = cases.synthetic_condition(ds[0] * 8, ds[1] * 8)
+        pipe.control_image_processor = type("P", (), {"preprocess": staticmethod(lambda image, height, width: image)})()
+        kw.update(condition_image=cond, controlnet_conditioning_scale=0.2)
+        okw.update(condition_image=cond, controlnet_conditioning_scale=0.2)
+    pipe.generate_image(prompts="p", negative_prompts="", height=H, width=W, num_inference_steps=steps,
+                        resampling_steps=R, progress=lambda it: it, rrg_scherduler_cls=ref.CosineScheduler,
+                        tiled_decoder=tiled, **kw)
+    ref_tail = torch.rand(3)
+
+    orc, _ = make_oracle(sd, 128 if xl else 64, vbs, controlnet=cn, patch=patch)
+    orc.seed_everything(seed)
+    img, info = orc.generate_image("p", "", height=H, width=W, num_inference_steps=steps, resampling_steps=R,
+                                   tiled_decoder=tiled, **okw)
+    assert torch.equal(info["latent"], cap["z"])
+    assert torch.equal(img, cap["img"])
+    assert torch.equal(torch.rand(3), ref_tail)
