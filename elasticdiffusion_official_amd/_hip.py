@@ -1,0 +1,80 @@
+"""Loader / builder for libelastic_hip.so (the C ABI declared in include/elastic_hip.h).
+
+The library is built in-tree by ``hipcc --offload-arch=gfx950`` (``build_library``; driven by
+``__graft_entry__.build()``) and loaded with ctypes *after* ``import torch`` so that the process holds one HIP
+runtime (libamdhip64.so.7, the SONAME torch-ROCm bundles).  There is NO fallback: if the shared object is missing or
+does not load, every product entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be imported before the .so so libamdhip64 is already resident)
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT_DIR = os.path.dirname(PKG_DIR)
+SRC = os.path.join(PKG_DIR, "csrc", "elastic_kernels.hip")
+INCLUDE = os.path.join(ROOT_DIR, "include")
+SO_PATH = os.path.join(PKG_DIR, "libelastic_hip.so")
+ABI_VERSION = 1
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> argtypes; mirrors include/elastic_hip.h one to one (tests/test_abi.py checks header <-> this table <-> .so)
+SIGNATURES = {
+    "ed_version": [],
+    "ed_error_string": [_i],
+    "ed_gather_views": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp],
+    "ed_scatter_centres": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "ed_pick_assemble": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_unpad_direction": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_fill_directions": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_cfg_ddim_step": [_vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _vp],
+    "ed_undo_step": [_vp, _vp, _vp, _vp, _i, _i64, _vp],
+    "ed_rrg_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_gather2d": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ed_tile_gather_pad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp],
+    "ed_tile_accumulate_normalise": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+}
+
+_LIB = None
+
+
+def build_library(force=False, verbose=False):
+    """hipcc cross-compiles gfx950 without a GPU; the .so is git-ignored but travels to the GPU box."""
+    if not force and os.path.isfile(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, "elastic_hip.h"))):
+        return SO_PATH
+    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE, SRC, "-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return SO_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: the HIP kernels are the product path and there is no CPU fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "ed_error_string" else ctypes.c_int
+        if L.ed_version() != ABI_VERSION:
+            raise RuntimeError(f"libelastic_hip.so ABI {L.ed_version()} != expected {ABI_VERSION}; rebuild")
+        _LIB = L
+    return _LIB
+
+
+def check(err, what):
+    if err != 0:
+        msg = lib().ed_error_string(err)
+        raise RuntimeError(f"{what}: HIP error {err} ({msg.decode() if msg else '?'})")

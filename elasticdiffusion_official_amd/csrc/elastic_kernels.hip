@@ -1,0 +1,552 @@
+// elastic_kernels.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the ElasticDiffusion hot path.
+//
+// Every kernel here is HBM/latency bound latent-space glue (gather / scatter / select / a few fp32 flops per
+// element); tensors are 64 KiB - 12 MiB, so the design rules are: one launch per logical phase, x-fastest
+// coalesced addressing (64 lanes x 4 B or 16 B contiguous), 16-byte vector access on the pure streaming kernels,
+// no atomics, no read-modify-write, no host sync.  MFMA is deliberately not used: nothing here is a contraction.
+//
+// fp32 arithmetic is written with explicit __fmul_rn/__fadd_rn/__fsub_rn/__fdiv_rn and the file is compiled with
+// -ffp-contract=off so no FMA is formed: results are bit-identical to the reference's torch-CPU op sequence.
+//
+// Interface documentation (and the reference file:line each entry replaces) lives in include/elastic_hip.h.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "elastic_hip.h"
+
+#define ED_ABI_VERSION 1
+#define ED_BLOCK 256
+
+namespace {
+
+// ---- element type adapters (model-boundary tensors may be f32 / f16 / bf16) -----------------------
+struct F32 { using type = float; };
+struct F16 { using type = __half; };
+struct BF16 { using type = uint16_t; };
+
+template <typename Tag> __device__ __forceinline__ float ld(const void* p, int64_t i);
+template <> __device__ __forceinline__ float ld<F32>(const void* p, int64_t i) { return ((const float*)p)[i]; }
+template <> __device__ __forceinline__ float ld<F16>(const void* p, int64_t i) { return __half2float(((const __half*)p)[i]); }
+template <> __device__ __forceinline__ float ld<BF16>(const void* p, int64_t i) {
+  return __uint_as_float(((uint32_t)((const uint16_t*)p)[i]) << 16);
+}
+
+template <typename Tag> __device__ __forceinline__ void st(void* p, int64_t i, float v);
+template <> __device__ __forceinline__ void st<F32>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ __forceinline__ void st<F16>(void* p, int64_t i, float v) { ((__half*)p)[i] = __float2half_rn(v); }
+template <> __device__ __forceinline__ void st<BF16>(void* p, int64_t i, float v) {
+  uint32_t u = __float_as_uint(v);
+  uint16_t r;
+  if ((u & 0x7fffffffu) > 0x7f800000u) {
+    r = 0x7fc0;  // NaN
+  } else {
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even, like torch
+    r = (uint16_t)(u >> 16);
+  }
+  ((uint16_t*)p)[i] = r;
+}
+
+inline int grid_for(int64_t n, int per_thread = 1) {
+  int64_t t = (n + per_thread - 1) / per_thread;
+  int64_t g = (t + ED_BLOCK - 1) / ED_BLOCK;
+  return (int)(g < 1 ? 1 : g);
+}
+
+inline int done() { return (int)hipGetLastError(); }
+
+// ---- ed_gather_views / ed_tile_gather_pad ----------------------------------------------------------
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_gather_windows(const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
+                 const int32_t* __restrict__ wy0, const int32_t* __restrict__ wx0, int V, int Sh, int Sw,
+                 int PH, int PW, int off_y, int off_x, const float* __restrict__ frame, float divisor, int use_div) {
+  int64_t n = (int64_t)V * B * C * PH * PW;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int x = (int)(t % PW);
+  int64_t r = t / PW;
+  int y = (int)(r % PH);
+  r /= PH;
+  int c = (int)(r % C);
+  r /= C;  // row = v*B + b
+  int b = (int)(r % B);
+  int v = (int)(r / B);
+  int yy = y - off_y, xx = x - off_x;
+  float val;
+  if (yy >= 0 && yy < Sh && xx >= 0 && xx < Sw) {
+    int sy = wy0[v] + yy, sx = wx0[v] + xx;
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+      val = latent[(((int64_t)b * C + c) * H + sy) * W + sx];
+      if (use_div) val = __fdiv_rn(val, divisor);
+    } else {
+      val = 0.0f;
+    }
+  } else {
+    val = frame ? frame[((int64_t)c * PH + y) * PW + x] : 0.0f;
+  }
+  st<Tag>(out, t, val);
+}
+
+// ---- ed_scatter_centres ----------------------------------------------------------------------------
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_scatter_centres(const void* __restrict__ pred, float* __restrict__ local, int B, int C, int H, int W,
+                  int PH, int PW, int ncb, const int32_t* __restrict__ row_blk, const int32_t* __restrict__ row_src,
+                  const int32_t* __restrict__ col_blk, const int32_t* __restrict__ col_src) {
+  int64_t n = (int64_t)B * C * H * W;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int X = (int)(t % W);
+  int64_t r = t / W;
+  int Y = (int)(r % H);
+  r /= H;
+  int c = (int)(r % C);
+  int b = (int)(r / C);
+  float cur = 0.0f;
+  bool settled = false;
+#pragma unroll
+  for (int kr = 0; kr < 2; ++kr) {
+    int rb = row_blk[Y * 2 + kr];
+    if (rb < 0 || settled) continue;
+    int sy = row_src[Y * 2 + kr];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      int cb = col_blk[X * 2 + kc];
+      if (cb < 0 || settled) continue;
+      int sx = col_src[X * 2 + kc];
+      int64_t row = (int64_t)(rb * ncb + cb) * B + b;
+      cur = ld<Tag>(pred, ((row * C + c) * PH + sy) * PW + sx);
+      if (cur != 0.0f) settled = true;  // NaN != 0 is true, as in torch
+    }
+  }
+  local[t] = cur;
+}
+
+// ---- ed_pick_assemble ------------------------------------------------------------------------------
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_pick_assemble(const float* __restrict__ latent, const uint8_t* __restrict__ idx,
+                const int32_t* __restrict__ src_row, const int32_t* __restrict__ src_col,
+                const float* __restrict__ frame, void* __restrict__ out, float* __restrict__ low,
+                int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x) {
+  int64_t n = (int64_t)K * B * C * PH * PW;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int x = (int)(t % PW);
+  int64_t r = t / PW;
+  int y = (int)(r % PH);
+  r /= PH;
+  int c = (int)(r % C);
+  r /= C;
+  int b = (int)(r % B);
+  int k = (int)(r / B);
+  int i = y - off_y, j = x - off_x;
+  float val;
+  if (i >= 0 && i < h && j >= 0 && j < w) {
+    int q = idx[(int64_t)k * h * w + (int64_t)i * w + j];
+    int sy = src_row[2 * i + (q >> 1)];
+    int sx = src_col[2 * j + (q & 1)];
+    val = latent[(((int64_t)b * C + c) * H + sy) * W + sx];
+    if (low) low[((((int64_t)k * B + b) * C + c) * h + i) * w + j] = val;
+  } else {
+    val = frame ? frame[((int64_t)c * PH + y) * PW + x] : 0.0f;
+  }
+  int64_t plane = (int64_t)PH * PW;
+  int64_t e = ((int64_t)c * PH + y) * PW + x;
+  int64_t row_u = ((int64_t)k * 2 + 0) * B + b;
+  int64_t row_c = ((int64_t)k * 2 + 1) * B + b;
+  st<Tag>(out, row_u * C * plane + e, val);
+  st<Tag>(out, row_c * C * plane + e, val);
+}
+
+// ---- ed_unpad_direction ----------------------------------------------------------------------------
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_unpad_direction(const void* __restrict__ uo, float* __restrict__ dirs, float* __restrict__ uncond_last,
+                  int K, int B, int C, int h, int w, int PH, int PW, int off_y, int off_x) {
+  int64_t n = (int64_t)K * B * C * h * w;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int j = (int)(t % w);
+  int64_t r = t / w;
+  int i = (int)(r % h);
+  r /= h;
+  int c = (int)(r % C);
+  r /= C;
+  int b = (int)(r % B);
+  int k = (int)(r / B);
+  int64_t plane = (int64_t)PH * PW;
+  int64_t e = ((int64_t)c * PH + (i + off_y)) * PW + (j + off_x);
+  float u = ld<Tag>(uo, (((int64_t)k * 2 + 0) * B + b) * C * plane + e);
+  float cd = ld<Tag>(uo, (((int64_t)k * 2 + 1) * B + b) * C * plane + e);
+  dirs[t] = __fsub_rn(cd, u);
+  if (uncond_last && k == K - 1) uncond_last[(((int64_t)b * C + c) * h + i) * w + j] = u;
+}
+
+// ---- ed_fill_directions ----------------------------------------------------------------------------
+__device__ __forceinline__ int last_covering_step(const uint8_t* __restrict__ idx, const int32_t* __restrict__ inv_row,
+                                                  const int32_t* __restrict__ inv_col, int K, int h, int w, int Y, int X) {
+  int r0 = inv_row[Y * 2], r1 = inv_row[Y * 2 + 1];
+  int c0 = inv_col[X * 2], c1 = inv_col[X * 2 + 1];
+  int64_t N = (int64_t)h * w;
+  for (int k = K - 1; k >= 0; --k) {
+    const uint8_t* ik = idx + (int64_t)k * N;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int rr = a ? r1 : r0;
+      if (rr < 0) continue;
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) {
+        int cc = bq ? c1 : c0;
+        if (cc < 0) continue;
+        int q = ik[(int64_t)(rr >> 1) * w + (cc >> 1)];
+        if (q == ((rr & 1) * 2 + (cc & 1))) return k;
+      }
+    }
+  }
+  return K - 1;  // fill_all: what no pick reached takes the last step's upsample (ED:643-644)
+}
+
+__global__ void __launch_bounds__(ED_BLOCK)
+k_fill_directions(const float* __restrict__ dirs, const uint8_t* __restrict__ idx,
+                  const int32_t* __restrict__ inv_row, const int32_t* __restrict__ inv_col,
+                  const int32_t* __restrict__ up_row, const int32_t* __restrict__ up_col,
+                  const int32_t* __restrict__ down_row, const int32_t* __restrict__ down_col,
+                  float* __restrict__ target, float* __restrict__ low_dir,
+                  int K, int B, int C, int H, int W, int h, int w) {
+  int64_t nfull = (int64_t)H * W;
+  int64_t nlow = low_dir ? (int64_t)h * w : 0;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= nfull + nlow) return;
+  int Y, X;
+  float* dst;
+  int64_t dplane, doff;
+  if (t < nfull) {
+    Y = (int)(t / W);
+    X = (int)(t % W);
+    dst = target;
+    dplane = nfull;
+    doff = t;
+  } else {
+    int64_t u = t - nfull;
+    int i = (int)(u / w), j = (int)(u % w);
+    Y = down_row[i];
+    X = down_col[j];
+    dst = low_dir;
+    dplane = (int64_t)h * w;
+    doff = u;
+  }
+  int k = last_covering_step(idx, inv_row, inv_col, K, h, w, Y, X);
+  int64_t lplane = (int64_t)h * w;
+  int64_t src = (int64_t)up_row[Y] * w + up_col[X];
+  int BC = B * C;
+  for (int bc = 0; bc < BC; ++bc)
+    dst[(int64_t)bc * dplane + doff] = dirs[((int64_t)k * BC + bc) * lplane + src];
+}
+
+// ---- ed_cfg_ddim_step ------------------------------------------------------------------------------
+__device__ __forceinline__ void ddim_one(float l, float d, float xv, float g, float sb, float sa, float sp, float sd,
+                                         float& prev, float& x0) {
+  float eps = __fadd_rn(l, __fmul_rn(g, d));
+  x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(sb, eps)), sa);
+  prev = __fadd_rn(__fmul_rn(sp, x0), __fmul_rn(sd, eps));
+}
+
+__global__ void __launch_bounds__(ED_BLOCK)
+k_cfg_ddim_v4(const float4* __restrict__ local, const float4* __restrict__ dir, const float4* __restrict__ x,
+              float4* __restrict__ prev, float4* __restrict__ x0, float g, float sb, float sa, float sp, float sd,
+              int64_t n4) {
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n4) return;
+  float4 l = local[t], d = dir[t], xv = x[t], p, o;
+  ddim_one(l.x, d.x, xv.x, g, sb, sa, sp, sd, p.x, o.x);
+  ddim_one(l.y, d.y, xv.y, g, sb, sa, sp, sd, p.y, o.y);
+  ddim_one(l.z, d.z, xv.z, g, sb, sa, sp, sd, p.z, o.z);
+  ddim_one(l.w, d.w, xv.w, g, sb, sa, sp, sd, p.w, o.w);
+  prev[t] = p;
+  x0[t] = o;
+}
+
+__global__ void __launch_bounds__(ED_BLOCK)
+k_cfg_ddim_s(const float* __restrict__ local, const float* __restrict__ dir, const float* __restrict__ x,
+             float* __restrict__ prev, float* __restrict__ x0, float g, float sb, float sa, float sp, float sd,
+             int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  float p, o;
+  ddim_one(local[t], dir[t], x[t], g, sb, sa, sp, sd, p, o);
+  prev[t] = p;
+  x0[t] = o;
+}
+
+// ---- ed_undo_step ----------------------------------------------------------------------------------
+// n_sub independent 16-byte loads per lane are issued before the dependent chain -> deep memory-level parallelism.
+__global__ void __launch_bounds__(ED_BLOCK)
+k_undo_v4(const float4* __restrict__ x_in, const float4* __restrict__ noise, const float2* __restrict__ coef,
+          float4* __restrict__ x_out, int n_sub, int64_t n4) {
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n4) return;
+  float4 xv = x_in[t];
+  int k = 0;
+  for (; k + 4 <= n_sub; k += 4) {
+    float4 z0 = noise[(int64_t)(k + 0) * n4 + t];
+    float4 z1 = noise[(int64_t)(k + 1) * n4 + t];
+    float4 z2 = noise[(int64_t)(k + 2) * n4 + t];
+    float4 z3 = noise[(int64_t)(k + 3) * n4 + t];
+    float2 c0 = coef[k], c1 = coef[k + 1], c2 = coef[k + 2], c3 = coef[k + 3];
+#define ED_UNDO(NZ, CF)                                             \
+  xv.x = __fadd_rn(__fmul_rn(CF.x, xv.x), __fmul_rn(CF.y, NZ.x)); \
+  xv.y = __fadd_rn(__fmul_rn(CF.x, xv.y), __fmul_rn(CF.y, NZ.y)); \
+  xv.z = __fadd_rn(__fmul_rn(CF.x, xv.z), __fmul_rn(CF.y, NZ.z)); \
+  xv.w = __fadd_rn(__fmul_rn(CF.x, xv.w), __fmul_rn(CF.y, NZ.w));
+    ED_UNDO(z0, c0) ED_UNDO(z1, c1) ED_UNDO(z2, c2) ED_UNDO(z3, c3)
+  }
+  for (; k < n_sub; ++k) {
+    float4 z = noise[(int64_t)k * n4 + t];
+    float2 c = coef[k];
+    ED_UNDO(z, c)
+  }
+#undef ED_UNDO
+  x_out[t] = xv;
+}
+
+__global__ void __launch_bounds__(ED_BLOCK)
+k_undo_s(const float* __restrict__ x_in, const float* __restrict__ noise, const float2* __restrict__ coef,
+         float* __restrict__ x_out, int n_sub, int64_t n) {
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  float xv = x_in[t];
+  for (int k = 0; k < n_sub; ++k) {
+    float2 c = coef[k];
+    xv = __fadd_rn(__fmul_rn(c.x, xv), __fmul_rn(c.y, noise[(int64_t)k * n + t]));
+  }
+  x_out[t] = xv;
+}
+
+// ---- ed_rrg_update ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ED_BLOCK)
+k_rrg_update(const float* __restrict__ prev, const float* __restrict__ x0, const float* __restrict__ low_latent,
+             const float* __restrict__ low_uncond, const float* __restrict__ low_dir,
+             const int32_t* __restrict__ up_row, const int32_t* __restrict__ up_col, float* __restrict__ out,
+             float g, float sb, float sa, float norm, float weight, int B, int C, int H, int W, int h, int w) {
+  int64_t n = (int64_t)B * C * H * W;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int X = (int)(t % W);
+  int64_t r = t / W;
+  int Y = (int)(r % H);
+  int64_t bc = r / H;
+  int64_t s = (bc * h + up_row[Y]) * w + up_col[X];
+  float eps = __fadd_rn(low_uncond[s], __fmul_rn(g, low_dir[s]));
+  float up = __fdiv_rn(__fsub_rn(low_latent[s], __fmul_rn(sb, eps)), sa);
+  float grad = __fmul_rn(__fmul_rn(norm, __fsub_rn(x0[t], up)), weight);  // d/dx0 of weight*mse(up, x0)
+  out[t] = __fadd_rn(prev[t], -grad);
+}
+
+// ---- ed_gather2d -----------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_gather2d(const void* __restrict__ in, void* __restrict__ out, int C, int H, int W,
+           const int32_t* __restrict__ src_n, const int32_t* __restrict__ rows, const int32_t* __restrict__ cols,
+           int N, int oh, int ow) {
+  int64_t n = (int64_t)N * C * oh * ow;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int j = (int)(t % ow);
+  int64_t r = t / ow;
+  int i = (int)(r % oh);
+  r /= oh;
+  int c = (int)(r % C);
+  int m = (int)(r / C);
+  int sy = rows[(int64_t)m * oh + i], sx = cols[(int64_t)m * ow + j];
+  float v = 0.0f;
+  if (sy >= 0 && sx >= 0) v = ld<TI>(in, (((int64_t)src_n[m] * C + c) * H + sy) * W + sx);
+  st<TO>(out, t, v);
+}
+
+// ---- ed_tile_accumulate_normalise ------------------------------------------------------------------
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_tile_accumulate(const void* __restrict__ dec, float* __restrict__ image, int B, int Cimg, int HP, int WP, int TP,
+                  int nct, const int32_t* __restrict__ row_tile, const int32_t* __restrict__ row_src,
+                  const int32_t* __restrict__ col_tile, const int32_t* __restrict__ col_src) {
+  int64_t n = (int64_t)B * Cimg * HP * WP;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int X = (int)(t % WP);
+  int64_t r = t / WP;
+  int Y = (int)(r % HP);
+  r /= HP;
+  int c = (int)(r % Cimg);
+  int b = (int)(r / Cimg);
+  float sum = 0.0f, cnt = 0.0f;
+  for (int kr = 0; kr < ED_TILE_MAXC; ++kr) {
+    int rb = row_tile[Y * ED_TILE_MAXC + kr];
+    if (rb < 0) break;
+    int sy = row_src[Y * ED_TILE_MAXC + kr];
+    for (int kc = 0; kc < ED_TILE_MAXC; ++kc) {
+      int cb = col_tile[X * ED_TILE_MAXC + kc];
+      if (cb < 0) break;
+      int sx = col_src[X * ED_TILE_MAXC + kc];
+      int64_t row = (int64_t)(rb * nct + cb) * B + b;
+      float v = ld<Tag>(dec, ((row * Cimg + c) * TP + sy) * TP + sx);
+      v = __fadd_rn(__fdiv_rn(v, 2.0f), 0.5f);
+      v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);  // clamp(0,1); NaN stays NaN like torch.clamp
+      sum = __fadd_rn(sum, v);
+      cnt = __fadd_rn(cnt, 1.0f);
+    }
+  }
+  image[t] = __fdiv_rn(sum, cnt);
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+#define ED_LAUNCH_T(dtype, KERNEL, n, ...)                                                       \
+  switch (dtype) {                                                                               \
+    case ED_F32: KERNEL<F32><<<grid_for(n), ED_BLOCK, 0, (hipStream_t)stream>>>(__VA_ARGS__); break;   \
+    case ED_F16: KERNEL<F16><<<grid_for(n), ED_BLOCK, 0, (hipStream_t)stream>>>(__VA_ARGS__); break;   \
+    case ED_BF16: KERNEL<BF16><<<grid_for(n), ED_BLOCK, 0, (hipStream_t)stream>>>(__VA_ARGS__); break; \
+    default: return (int)hipErrorInvalidValue;                                                   \
+  }
+#define ED_LAUNCH(KERNEL, n, ...) KERNEL<<<grid_for(n), ED_BLOCK, 0, (hipStream_t)stream>>>(__VA_ARGS__)
+
+extern "C" {
+
+int ed_version(void) { return ED_ABI_VERSION; }
+
+const char* ed_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int ed_gather_views(const float* latent, void* out, int dtype, int B, int C, int H, int W, const int32_t* win_y0,
+                    const int32_t* win_x0, int V, int Sh, int Sw, int PH, int PW, int off_y, int off_x,
+                    const float* frame, float divisor, void* stream) {
+  int64_t n = (int64_t)V * B * C * PH * PW;
+  if (n == 0) return 0;
+  int use_div = divisor != 1.0f;
+  ED_LAUNCH_T(dtype, k_gather_windows, n, latent, out, B, C, H, W, win_y0, win_x0, V, Sh, Sw, PH, PW, off_y, off_x,
+                                         frame, divisor, use_div);
+  return done();
+}
+
+int ed_tile_gather_pad(const float* latent, void* tiles, int dtype, int B, int C, int H, int W, const int32_t* tile_y0,
+                       const int32_t* tile_x0, int T_, int Ts, float scaling_factor, void* stream) {
+  return ed_gather_views(latent, tiles, dtype, B, C, H, W, tile_y0, tile_x0, T_, Ts, Ts, Ts, Ts, 0, 0, nullptr,
+                         scaling_factor, stream);
+}
+
+int ed_scatter_centres(const void* pred, int dtype, float* local, int B, int C, int H, int W, int PH, int PW,
+                       int n_col_blocks, const int32_t* row_blk, const int32_t* row_src, const int32_t* col_blk,
+                       const int32_t* col_src, void* stream) {
+  int64_t n = (int64_t)B * C * H * W;
+  if (n == 0) return 0;
+  ED_LAUNCH_T(dtype, k_scatter_centres, n, pred, local, B, C, H, W, PH, PW, n_col_blocks, row_blk, row_src, col_blk,
+                                         col_src);
+  return done();
+}
+
+int ed_pick_assemble(const float* latent, const uint8_t* idx, const int32_t* src_row, const int32_t* src_col,
+                     const float* frame, void* out, int dtype, float* low, int K, int B, int C, int H, int W, int h,
+                     int w, int PH, int PW, int off_y, int off_x, void* stream) {
+  int64_t n = (int64_t)K * B * C * PH * PW;
+  if (n == 0) return 0;
+  ED_LAUNCH_T(dtype, k_pick_assemble, n, latent, idx, src_row, src_col, frame, out, low, K, B, C, H, W, h, w, PH, PW,
+                                         off_y, off_x);
+  return done();
+}
+
+int ed_unpad_direction(const void* unet_out, int dtype, float* dirs, float* uncond_last, int K, int B, int C, int h,
+                       int w, int PH, int PW, int off_y, int off_x, void* stream) {
+  int64_t n = (int64_t)K * B * C * h * w;
+  if (n == 0) return 0;
+  ED_LAUNCH_T(dtype, k_unpad_direction, n, unet_out, dirs, uncond_last, K, B, C, h, w, PH, PW, off_y, off_x);
+  return done();
+}
+
+int ed_fill_directions(const float* dirs, const uint8_t* idx, const int32_t* inv_row, const int32_t* inv_col,
+                       const int32_t* up_row, const int32_t* up_col, const int32_t* down_row, const int32_t* down_col,
+                       float* target, float* low_dir, int K, int B, int C, int H, int W, int h, int w, void* stream) {
+  int64_t n = (int64_t)H * W + (low_dir ? (int64_t)h * w : 0);
+  if (n == 0 || K <= 0) return K <= 0 ? (int)hipErrorInvalidValue : 0;
+  ED_LAUNCH(k_fill_directions, n, dirs, idx, inv_row,
+                     inv_col, up_row, up_col, down_row, down_col, target, low_dir, K, B, C, H, W, h, w);
+  return done();
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+int ed_cfg_ddim_step(const float* local, const float* direction, const float* x, float* prev, float* x0, float g,
+                     float sqrt_beta_t, float sqrt_alpha_t, float sqrt_alpha_prev, float sqrt_one_minus_alpha_prev,
+                     int64_t n, void* stream) {
+  if (n == 0) return 0;
+  if ((n & 3) == 0 && aligned16(local) && aligned16(direction) && aligned16(x) && aligned16(prev) && aligned16(x0)) {
+    ED_LAUNCH(k_cfg_ddim_v4, n / 4, (const float4*)local, (const float4*)direction, (const float4*)x, (float4*)prev, (float4*)x0, g,
+                       sqrt_beta_t, sqrt_alpha_t, sqrt_alpha_prev, sqrt_one_minus_alpha_prev, n / 4);
+  } else {
+    ED_LAUNCH(k_cfg_ddim_s, n, local, direction, x,
+                       prev, x0, g, sqrt_beta_t, sqrt_alpha_t, sqrt_alpha_prev, sqrt_one_minus_alpha_prev, n);
+  }
+  return done();
+}
+
+int ed_undo_step(const float* x_in, const float* noise, const float* coef, float* x_out, int n_sub, int64_t n,
+                 void* stream) {
+  if (n == 0) return 0;
+  if ((n & 3) == 0 && aligned16(x_in) && aligned16(noise) && aligned16(x_out)) {
+    ED_LAUNCH(k_undo_v4, n / 4, (const float4*)x_in,
+                       (const float4*)noise, (const float2*)coef, (float4*)x_out, n_sub, n / 4);
+  } else {
+    ED_LAUNCH(k_undo_s, n, x_in, noise,
+                       (const float2*)coef, x_out, n_sub, n);
+  }
+  return done();
+}
+
+int ed_rrg_update(const float* prev, const float* x0, const float* low_latent, const float* low_uncond,
+                  const float* low_dir, const int32_t* up_row, const int32_t* up_col, float* out, float g,
+                  float sqrt_beta_t, float sqrt_alpha_t, float norm, float weight, int B, int C, int H, int W, int h,
+                  int w, void* stream) {
+  int64_t n = (int64_t)B * C * H * W;
+  if (n == 0) return 0;
+  ED_LAUNCH(k_rrg_update, n, prev, x0, low_latent,
+                     low_uncond, low_dir, up_row, up_col, out, g, sqrt_beta_t, sqrt_alpha_t, norm, weight, B, C, H, W,
+                     h, w);
+  return done();
+}
+
+int ed_gather2d(const void* in, int in_dtype, void* out, int out_dtype, int C, int H, int W, const int32_t* src_n,
+                const int32_t* rows, const int32_t* cols, int N, int oh, int ow, void* stream) {
+  int64_t n = (int64_t)N * C * oh * ow;
+  if (n == 0) return 0;
+#define ED_G2D(TI, TO) \
+  k_gather2d<TI, TO><<<grid_for(n), ED_BLOCK, 0, (hipStream_t)stream>>>(in, out, C, H, W, src_n, rows, cols, N, oh, ow)
+  int key = in_dtype * 3 + out_dtype;
+  switch (key) {
+    case 0: ED_G2D(F32, F32); break;
+    case 1: ED_G2D(F32, F16); break;
+    case 2: ED_G2D(F32, BF16); break;
+    case 3: ED_G2D(F16, F32); break;
+    case 4: ED_G2D(F16, F16); break;
+    case 5: ED_G2D(F16, BF16); break;
+    case 6: ED_G2D(BF16, F32); break;
+    case 7: ED_G2D(BF16, F16); break;
+    case 8: ED_G2D(BF16, BF16); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef ED_G2D
+  return done();
+}
+
+int ed_tile_accumulate_normalise(const void* decoded, int dtype, float* image, int B, int Cimg, int HP, int WP, int TP,
+                                 int n_col_tiles, const int32_t* row_tile, const int32_t* row_src,
+                                 const int32_t* col_tile, const int32_t* col_src, void* stream) {
+  int64_t n = (int64_t)B * Cimg * HP * WP;
+  if (n == 0) return 0;
+  ED_LAUNCH_T(dtype, k_tile_accumulate, n, decoded, image, B, Cimg, HP, WP, TP, n_col_tiles, row_tile, row_src, col_tile,
+                                         col_src);
+  return done();
+}
+
+}  // extern "C"

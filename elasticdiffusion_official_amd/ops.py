@@ -1,0 +1,196 @@
+"""Torch-tensor wrappers over the C ABI (include/elastic_hip.h).  PyTorch is only plumbing here: it owns the device
+buffers and the stream; every wrapper validates its arguments, passes raw device pointers and raises on a HIP
+error.  No wrapper has a fallback path -- a tensor that is not on a ROCm device is an error."""
+import torch
+
+from . import _hip
+
+ED_F32, ED_F16, ED_BF16 = 0, 1, 2
+_DTYPE = {torch.float32: ED_F32, torch.float16: ED_F16, torch.bfloat16: ED_BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on the MI355X (got {type(t).__name__}"
+                           f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _opt(t, dtype=None, name="tensor"):
+    return None if t is None else _dev(t, dtype, name)
+
+
+def _code(t, name):
+    try:
+        return _DTYPE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"{name}: unsupported dtype {t.dtype}") from None
+
+
+def gather_views(latent, out, win_y0, win_x0, Sh, Sw, off_y=0, off_x=0, frame=None, divisor=1.0):
+    """latent f32 [B,C,H,W] -> out [(V*B),C,PH,PW] (row = v*B+b).  See ed_gather_views."""
+    B, C, H, W = latent.shape
+    V = win_y0.numel()
+    rows, C2, PH, PW = out.shape
+    assert rows == V * B and C2 == C and win_x0.numel() == V
+    assert off_y >= 0 and off_x >= 0 and off_y + Sh <= PH and off_x + Sw <= PW
+    if frame is not None:
+        assert tuple(frame.shape) == (C, PH, PW)
+    err = _hip.lib().ed_gather_views(_dev(latent, torch.float32, "latent"), _dev(out, None, "out"), _code(out, "out"),
+                                     B, C, H, W, _dev(win_y0, torch.int32, "win_y0"), _dev(win_x0, torch.int32, "win_x0"),
+                                     V, Sh, Sw, PH, PW, off_y, off_x, _opt(frame, torch.float32, "frame"),
+                                     float(divisor), _stream())
+    _hip.check(err, "ed_gather_views")
+    return out
+
+
+def scatter_centres(pred, local, n_col_blocks, row_blk, row_src, col_blk, col_src):
+    """pred [(V*B),C,PH,PW] -> local f32 [B,C,H,W], first writer (by value) wins.  See ed_scatter_centres."""
+    B, C, H, W = local.shape
+    rows, C2, PH, PW = pred.shape
+    assert C2 == C and rows % B == 0
+    assert row_blk.numel() == H * 2 == row_src.numel() and col_blk.numel() == W * 2 == col_src.numel()
+    err = _hip.lib().ed_scatter_centres(_dev(pred, None, "pred"), _code(pred, "pred"), _dev(local, torch.float32, "local"),
+                                        B, C, H, W, PH, PW, n_col_blocks,
+                                        _dev(row_blk, torch.int32), _dev(row_src, torch.int32),
+                                        _dev(col_blk, torch.int32), _dev(col_src, torch.int32), _stream())
+    _hip.check(err, "ed_scatter_centres")
+    return local
+
+
+def pick_assemble(latent, idx, src_row, src_col, out, h, w, off_y=0, off_x=0, frame=None, low=None):
+    """latent f32 [B,C,H,W], idx u8 [K,h*w] -> out [(K*2*B),C,PH,PW], low f32 [K,B,C,h,w].  See ed_pick_assemble."""
+    B, C, H, W = latent.shape
+    K = idx.shape[0]
+    rows, C2, PH, PW = out.shape
+    assert rows == K * 2 * B and C2 == C and idx.shape[1] == h * w
+    assert src_row.numel() == 2 * h and src_col.numel() == 2 * w
+    assert off_y + h <= PH and off_x + w <= PW
+    if frame is not None:
+        assert tuple(frame.shape) == (C, PH, PW)
+    if low is not None:
+        assert tuple(low.shape) == (K, B, C, h, w)
+    err = _hip.lib().ed_pick_assemble(_dev(latent, torch.float32, "latent"), _dev(idx, torch.uint8, "idx"),
+                                      _dev(src_row, torch.int32), _dev(src_col, torch.int32),
+                                      _opt(frame, torch.float32, "frame"), _dev(out, None, "out"), _code(out, "out"),
+                                      _opt(low, torch.float32, "low"), K, B, C, H, W, h, w, PH, PW, off_y, off_x,
+                                      _stream())
+    _hip.check(err, "ed_pick_assemble")
+    return out
+
+
+def unpad_direction(unet_out, dirs, uncond_last, off_y=0, off_x=0):
+    """unet_out [(K*2*B),C,PH,PW] -> dirs f32 [K,B,C,h,w] (= cond - uncond), uncond_last f32 [B,C,h,w]."""
+    K, B, C, h, w = dirs.shape
+    rows, C2, PH, PW = unet_out.shape
+    assert rows == K * 2 * B and C2 == C
+    if uncond_last is not None:
+        assert tuple(uncond_last.shape) == (B, C, h, w)
+    err = _hip.lib().ed_unpad_direction(_dev(unet_out, None, "unet_out"), _code(unet_out, "unet_out"),
+                                        _dev(dirs, torch.float32, "dirs"), _opt(uncond_last, torch.float32, "uncond_last"),
+                                        K, B, C, h, w, PH, PW, off_y, off_x, _stream())
+    _hip.check(err, "ed_unpad_direction")
+    return dirs
+
+
+def fill_directions(dirs, idx, inv_row, inv_col, up_row, up_col, down_row, down_col, target, low_dir=None):
+    """dirs f32 [K,B,C,h,w] + idx u8 [K,h*w] -> target f32 [B,C,H,W] (+ low_dir f32 [B,C,h,w])."""
+    K, B, C, h, w = dirs.shape
+    B2, C2, H, W = target.shape
+    assert (B2, C2) == (B, C) and tuple(idx.shape) == (K, h * w)
+    assert inv_row.numel() == 2 * H and inv_col.numel() == 2 * W and up_row.numel() == H and up_col.numel() == W
+    assert down_row.numel() == h and down_col.numel() == w
+    err = _hip.lib().ed_fill_directions(_dev(dirs, torch.float32, "dirs"), _dev(idx, torch.uint8, "idx"),
+                                        _dev(inv_row, torch.int32), _dev(inv_col, torch.int32),
+                                        _dev(up_row, torch.int32), _dev(up_col, torch.int32),
+                                        _dev(down_row, torch.int32), _dev(down_col, torch.int32),
+                                        _dev(target, torch.float32, "target"), _opt(low_dir, torch.float32, "low_dir"),
+                                        K, B, C, H, W, h, w, _stream())
+    _hip.check(err, "ed_fill_directions")
+    return target
+
+
+def cfg_ddim_step(local, direction, x, prev, x0, g, sqrt_beta_t, sqrt_alpha_t, sqrt_alpha_prev, sqrt_1m_alpha_prev):
+    n = x.numel()
+    for t in (local, direction, prev, x0):
+        assert t.numel() == n
+    err = _hip.lib().ed_cfg_ddim_step(_dev(local, torch.float32), _dev(direction, torch.float32), _dev(x, torch.float32),
+                                      _dev(prev, torch.float32), _dev(x0, torch.float32), float(g), float(sqrt_beta_t),
+                                      float(sqrt_alpha_t), float(sqrt_alpha_prev), float(sqrt_1m_alpha_prev), n, _stream())
+    _hip.check(err, "ed_cfg_ddim_step")
+    return prev, x0
+
+
+def undo_step(x_in, noise, coef, x_out):
+    """noise f32 [n_sub, *x.shape], coef f32 [n_sub,2] on device."""
+    n = x_in.numel()
+    n_sub = noise.shape[0]
+    assert noise.numel() == n_sub * n and coef.numel() == 2 * n_sub and x_out.numel() == n
+    err = _hip.lib().ed_undo_step(_dev(x_in, torch.float32), _dev(noise, torch.float32), _dev(coef, torch.float32),
+                                  _dev(x_out, torch.float32), n_sub, n, _stream())
+    _hip.check(err, "ed_undo_step")
+    return x_out
+
+
+def rrg_update(prev, x0, low_latent, low_uncond, low_dir, up_row, up_col, out, g, sqrt_beta_t, sqrt_alpha_t, norm, weight):
+    B, C, H, W = prev.shape
+    h, w = low_latent.shape[-2:]
+    assert tuple(low_latent.shape) == (B, C, h, w) == tuple(low_uncond.shape) == tuple(low_dir.shape)
+    assert up_row.numel() == H and up_col.numel() == W
+    err = _hip.lib().ed_rrg_update(_dev(prev, torch.float32), _dev(x0, torch.float32), _dev(low_latent, torch.float32),
+                                   _dev(low_uncond, torch.float32), _dev(low_dir, torch.float32),
+                                   _dev(up_row, torch.int32), _dev(up_col, torch.int32), _dev(out, torch.float32),
+                                   float(g), float(sqrt_beta_t), float(sqrt_alpha_t), float(norm), float(weight),
+                                   B, C, H, W, h, w, _stream())
+    _hip.check(err, "ed_rrg_update")
+    return out
+
+
+def gather2d(inp, out, src_n, rows, cols):
+    """out[n,c,i,j] = inp[src_n[n],c,rows[n,i],cols[n,j]] (0 where an index is negative)."""
+    _, C, H, W = inp.shape
+    N, C2, oh, ow = out.shape
+    assert C2 == C and tuple(rows.shape) == (N, oh) and tuple(cols.shape) == (N, ow) and src_n.numel() == N
+    err = _hip.lib().ed_gather2d(_dev(inp, None, "inp"), _code(inp, "inp"), _dev(out, None, "out"), _code(out, "out"),
+                                 C, H, W, _dev(src_n, torch.int32), _dev(rows, torch.int32), _dev(cols, torch.int32),
+                                 N, oh, ow, _stream())
+    _hip.check(err, "ed_gather2d")
+    return out
+
+
+def tile_gather_pad(latent, tiles, tile_y0, tile_x0, scaling_factor):
+    """latent f32 [B,C,H,W] -> tiles [(T*B),C,Ts,Ts] = zero-haloed windows / scaling_factor."""
+    B, C, H, W = latent.shape
+    T = tile_y0.numel()
+    rows, C2, Ts, Ts2 = tiles.shape
+    assert rows == T * B and C2 == C and Ts == Ts2
+    err = _hip.lib().ed_tile_gather_pad(_dev(latent, torch.float32), _dev(tiles, None, "tiles"), _code(tiles, "tiles"),
+                                        B, C, H, W, _dev(tile_y0, torch.int32), _dev(tile_x0, torch.int32), T, Ts,
+                                        float(scaling_factor), _stream())
+    _hip.check(err, "ed_tile_gather_pad")
+    return tiles
+
+
+TILE_MAXC = 4
+
+
+def tile_accumulate_normalise(decoded, image, n_col_tiles, row_tile, row_src, col_tile, col_src):
+    """decoded [(T*B),3,TP,TP] raw VAE output -> image f32 [B,3,HP,WP] = mean over covering tiles of clamp(v/2+.5)."""
+    B, Cimg, HP, WP = image.shape
+    rows, C2, TP, TP2 = decoded.shape
+    assert C2 == Cimg and TP == TP2 and rows % B == 0
+    assert row_tile.numel() == HP * TILE_MAXC == row_src.numel() and col_tile.numel() == WP * TILE_MAXC == col_src.numel()
+    err = _hip.lib().ed_tile_accumulate_normalise(_dev(decoded, None, "decoded"), _code(decoded, "decoded"),
+                                                  _dev(image, torch.float32), B, Cimg, HP, WP, TP, n_col_tiles,
+                                                  _dev(row_tile, torch.int32), _dev(row_src, torch.int32),
+                                                  _dev(col_tile, torch.int32), _dev(col_src, torch.int32), _stream())
+    _hip.check(err, "ed_tile_accumulate_normalise")
+    return image

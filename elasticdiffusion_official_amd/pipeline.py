@@ -1,0 +1,447 @@
+"""MI355X-native drop-in for the hot path of the reference's ``ElasticDiffusion`` class
+(/root/reference/elastic_diffusion.py:110-1130, "ED:n" below; ControlNet variant "EDC:n" =
+elastic_diffusion_w_controlnet.py): same constructor and ``generate_image`` surface, same RNG stream as the
+reference's CPU path, but one timestep is
+
+    host   : pick-index draws (torch CPU generator, ED:501-544) + pad-strip reseed replay (ED:359)   -- no device sync
+    HIP    : ed_pick_assemble + ed_gather_views   -> ONE model-input batch: K CFG pairs + V views (all d x d)
+    torch  : ONE UNet forward for the whole batch (rows optionally sharded over ranks, all-gathered over RCCL)
+    HIP    : ed_unpad_direction, ed_fill_directions, ed_scatter_centres, ed_cfg_ddim_step
+    HIP    : [RePaint] ed_undo_step, then the same phase with K = 1 and guidance/3
+    HIP    : [RRG] ed_rrg_update
+
+instead of the reference's R+1 sequential batch-2 UNet calls, V/view_batch_size view calls and ~hundreds of eager
+tensor ops with host syncs per step.  The resampling steps can be batched because their inputs depend only on the RNG,
+never on each other's UNet outputs (ED:661-681): the sequential semantics live only in the overwrite order of the
+fill, which ed_fill_directions reproduces.
+
+There is no CPU path in this module: without the HIP library and a ROCm device it raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import geometry, host_rng, ops
+from .schedule import CosineScheduler, DDIMSchedule
+from .sharding import RowSharder
+
+
+def _identity_progress(it):
+    return it
+
+
+class _Stager:
+    """Pinned host staging ring: host RNG results are written into pinned memory and uploaded with an async copy;
+    a slot is reused only after its copy event has completed, so the host may run ahead of the GPU."""
+
+    def __init__(self, depth=4):
+        self.depth = depth
+        self.rings = {}
+
+    def host(self, shape, dtype):
+        key = (tuple(shape), dtype)
+        ring = self.rings.setdefault(key, {"slots": [], "next": 0})
+        k = ring["next"] % self.depth
+        ring["next"] += 1
+        if k >= len(ring["slots"]):
+            ring["slots"].append([torch.empty(shape, dtype=dtype, pin_memory=True), None])
+        slot = ring["slots"][k]
+        if slot[1] is not None:
+            slot[1].synchronize()  # the async upload that last used this slot must have finished
+        self._last = slot
+        return slot[0]
+
+    def upload(self, host_buf, device):
+        dev = torch.empty(host_buf.shape, dtype=host_buf.dtype, device=device)
+        dev.copy_(host_buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._last[1] = ev
+        return dev
+
+
+class ElasticDiffusion(nn.Module):
+    """Constructor signature of ED:111-115 plus keyword-only injection points (no pretrained weights, ``diffusers`` or
+    network exist in the build environment): ``unet``, ``vae``, ``scheduler``, ``text_encoder`` (callable
+    ``prompts -> (embeds, pooled)``), ``controlnet``, ``process_group``."""
+
+    def __init__(self, device, sd_version="2.0", verbose=False, log_freq=5, view_batch_size=1, low_vram=False, *,
+                 unet=None, vae=None, scheduler=None, text_encoder=None, controlnet=None, process_group=None,
+                 model_dtype=None, weights=None):
+        super().__init__()
+        device = torch.device(device)
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("elasticdiffusion_official_amd runs the hot path in HIP kernels on an MI355X; "
+                               f"device={device} is not a ROCm device and there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+        from . import _hip
+        _hip.lib()  # fail here, loudly, if the extension is missing
+        self.device = device
+        self.sd_version = sd_version
+        self.verbose = verbose
+        self.log_freq = log_freq
+        self.view_batch_size = view_batch_size
+        self.low_vram = low_vram
+        self.torch_dtype = torch.float32  # latent-space state is always fp32 (ED:121 uses fp16 only for low_vram)
+        xl = sd_version.startswith("XL")
+        if unet is None or vae is None:
+            from .models import build_models
+            built_unet, built_vae = build_models(sd_version, device=device, dtype=model_dtype, weights=weights)
+            unet = unet if unet is not None else built_unet
+            vae = vae if vae is not None else built_vae
+        self.unet = unet.to(device)
+        self.vae = vae.to(device)
+        self.controlnet = controlnet.to(device) if controlnet is not None else None
+        self.scheduler = scheduler if scheduler is not None else DDIMSchedule()
+        self.text_encoder = text_encoder
+        self.model_size = 128 if xl else 64  # d_H, d_W of ED:398-400
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)  # ED:156
+        self.sharder = RowSharder(process_group)
+        self.set_view_config()
+        self.default_size = None
+        self._stager = _Stager()
+        self.last_latents = None
+        self.stats = {}
+
+    # ---- small API surface the reference's callers use (APP:35-39, ED:159-171, 943-950) -----------------
+    def set_view_config(self, patch_size=None):
+        s = self.unet.config.sample_size
+        w = patch_size if patch_size is not None else s // 2
+        self.view_config = {"window_size": w, "stride": w, "context_size": s - w}
+
+    def seed_everything(self, seed, seed_np=True):
+        host_rng.seed_everything(seed, seed_np)
+
+    def get_downsample_size(self, H, W):
+        return geometry.reduced_size(H, W, self.sd_version, self.vae_scale_factor)
+
+    def get_views(self, panorama_height, panorama_width, h_ws=64, w_ws=64, stride=32, **kwargs):
+        s = self.vae_scale_factor
+        if panorama_height % s or panorama_width % s:
+            raise ValueError(f"height {panorama_height} and Width {panorama_width} must be divisable by {s}")
+        rows = geometry.axis_windows(panorama_height // s, h_ws, stride)
+        cols = geometry.axis_windows(panorama_width // s, w_ws, stride)
+        return [(r[0], r[1], c[0], c[1]) for r in rows for c in cols]
+
+    @property
+    def model_dtype(self):
+        return next(self.unet.parameters()).dtype
+
+    @torch.no_grad()
+    def get_text_embeds(self, prompt):
+        """ED:254-265.  With no CLIP weights available the default is a deterministic synthetic embedding per prompt
+        string (shape-compatible: (B,77,cross_attention_dim) and the pooled (B,projection_dim))."""
+        if self.text_encoder is not None:
+            e, p = self.text_encoder(prompt)
+            return e.to(self.device), p.to(self.device)
+        cfg = self.unet.config
+        D = getattr(cfg, "cross_attention_dim", 768)
+        P = getattr(cfg, "pooled_projection_dim", None)
+        embeds, pooled = [], []
+        for s in ([prompt] if isinstance(prompt, str) else prompt):
+            g = torch.Generator().manual_seed(host_rng.strip_seed("prompt", 0, 0, 0, s))
+            e = torch.randn(1, 77, D, generator=g)
+            embeds.append(e)
+            pooled.append(torch.randn(1, P, generator=g) if P else e)
+        return torch.cat(embeds).to(self.device), torch.cat(pooled).to(self.device)
+
+    # ---- per-image setup ---------------------------------------------------------------------------
+    def _dev_i32(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def _plan(self, height, width):
+        s = self.vae_scale_factor
+        if height % s or width % s:
+            raise ValueError(f"height {height} and Width {width} must be divisable by {s}")  # ED:200-201
+        Hl, Wl = height // s, width // s
+        h, w = self.get_downsample_size(height, width)
+        vc = self.view_config
+        P = type("Plan", (), {})()
+        P.Hl, P.Wl, P.h, P.w = Hl, Wl, h, w
+        P.pick = geometry.PickPlan(Hl, Wl, h, w)
+        P.views = geometry.ViewPlan(Hl, Wl, vc["window_size"], vc["stride"], vc["context_size"])
+        P.gpad = geometry.PadPlan(h, w, self.model_size)
+        P.vpad = geometry.PadPlan(P.views.Sh, P.views.Sw, self.model_size)
+        P.one_batch = (P.gpad.PH, P.gpad.PW) == (P.vpad.PH, P.vpad.PW)
+        d = self._dev_i32
+        P.src_row, P.src_col = d(P.pick.src_row), d(P.pick.src_col)
+        P.inv_row, P.inv_col = d(P.pick.inv_row), d(P.pick.inv_col)
+        P.up_row, P.up_col = d(P.pick.up_row), d(P.pick.up_col)
+        P.down_row, P.down_col = d(P.pick.down_row), d(P.pick.down_col)
+        P.win_y0, P.win_x0 = d(P.views.win_y0), d(P.views.win_x0)
+        rb, rs, cb, cs = P.views.cover_tables(P.vpad.top, P.vpad.left)
+        P.row_blk, P.row_src, P.col_blk, P.col_src = d(rb), d(rs), d(cb), d(cs)
+        P.sampler = host_rng.PickSampler(P.pick.N)
+        return P
+
+    @torch.no_grad()
+    def _strip_frames(self, pad, timesteps, C):
+        """All noised-background frames [T,C,PH,PW] of one PadPlan (ED:327-391), computed once per image instead of
+        2 VAE encodes per global UNet call (the reference's TODO at ED:340).  Contents depend only on
+        (dim, side, size, t); the draws come from md5-seeded private generators (host_rng.strip_draws)."""
+        T = len(timesteps)
+        if not pad.padded:
+            return None
+        frames = torch.zeros(T, C, pad.PH, pad.PW, device=self.device, dtype=torch.float32)
+        sf = self.vae.config.scaling_factor
+        s = self.vae_scale_factor
+        vae_dtype = next(self.vae.parameters()).dtype
+        for (dim, side, Hs, Ws, y0, x0) in pad.strips:
+            draws = [host_rng.strip_draws(dim, side, Hs, Ws, t, C) for t in timesteps]
+            colour = torch.cat([dr[0] for dr in draws]).to(self.device)
+            post = torch.cat([dr[1] for dr in draws]).to(self.device)
+            fwd = torch.cat([dr[2] for dr in draws]).to(self.device)
+            coef = torch.tensor([self.scheduler.add_noise_coefficients(t) for t in timesteps], dtype=torch.float32,
+                                device=self.device)
+            chunk = max(1, min(T, (64 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
+            for a in range(0, T, chunk):
+                b = min(T, a + chunk)
+                img = colour[a:b, :, None, None].expand(b - a, 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
+                dist = self.vae.encode(img).latent_dist
+                enc = (dist.mean.float() + dist.std.float() * post[a:b]) * sf
+                noised = coef[a:b, 0].view(-1, 1, 1, 1) * enc + coef[a:b, 1].view(-1, 1, 1, 1) * fwd[a:b]
+                frames[a:b, :, y0:y0 + Hs, x0:x0 + Ws] = noised
+        return frames
+
+    def _embed_rows(self, K, V, un, co, pun, pco):
+        """Text rows for one fused model batch: K x [uncond(B), cond(B)] then V x uncond(B)  (ED:436-438, 846-847)."""
+        dt = self.model_dtype
+        text = torch.cat([un, co] * K + [un] * V).to(dt).contiguous()
+        pooled = torch.cat([pun, pco] * K + [pun] * V).to(dt).contiguous()
+        return text, pooled
+
+    # ---- model boundary ----------------------------------------------------------------------------
+    def _run_model(self, x_rows, t_dev, text, pooled, cond_rows=None, cn_scale=1.0):
+        """ED:413-426 / EDC:476-518 for an arbitrary batch of d x d rows; rows are sharded across ranks."""
+        def fwd(x, txt, pl, cond):
+            kw = {}
+            if self.sd_version.startswith("XL"):
+                ids = self._time_ids.to(txt.dtype).expand(x.shape[0], -1)
+                kw["added_cond_kwargs"] = {"text_embeds": pl, "time_ids": ids}
+            if cond is not None:
+                down, mid = self.controlnet(x, t_dev, encoder_hidden_states=txt, controlnet_cond=cond,
+                                            conditioning_scale=cn_scale, guess_mode=False, return_dict=False, **kw)
+                kw["down_block_additional_residuals"], kw["mid_block_additional_residual"] = down, mid
+            return self.unet(x, t_dev, encoder_hidden_states=txt, **kw)["sample"].contiguous()
+
+        return self.sharder.run(fwd, x_rows, text, pooled, cond_rows)
+
+    # ---- one estimation phase (ED:1016-1035 or ED:1043-1056) ---------------------------------------
+    def _phase(self, P, x, ti, K, g, drop_p, emb, cond=None):
+        B, C = x.shape[:2]
+        dev, mdt = self.device, self.model_dtype
+        t = self._timesteps[ti]
+        n_g, n_v = 2 * K * B, P.views.V * B
+        # host draws first (they never wait for the GPU)
+        idx_host = self._stager.host((K, P.pick.N), torch.uint8)
+        P.sampler.draw(K, drop_p, lambda: host_rng.replay_strip_reseeds(len(P.gpad.strips)), out=idx_host)
+        idx = self._stager.upload(idx_host, dev)
+        # view batches as the reference forms them: only their pad-strip reseeds are observable (ED:830, 359)
+        if P.vpad.strips:
+            for _ in range(math.ceil(P.views.V / self.view_batch_size)):
+                host_rng.replay_strip_reseeds(len(P.vpad.strips))
+        gframe = None if self._gframes is None else self._gframes[ti]
+        vframe = None if self._vframes is None else self._vframes[ti]
+        low = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
+        if P.one_batch:
+            rows = torch.empty(n_g + n_v, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
+            g_rows, v_rows = rows[:n_g], rows[n_g:]
+        else:
+            g_rows = torch.empty(n_g, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
+            v_rows = torch.empty(n_v, C, P.vpad.PH, P.vpad.PW, device=dev, dtype=mdt)
+        ops.pick_assemble(x, idx, P.src_row, P.src_col, g_rows, P.h, P.w, P.gpad.top, P.gpad.left, gframe, low)
+        ops.gather_views(x, v_rows, P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, vframe)
+        text, pooled = emb[K]
+        t_dev = self._t_dev[ti]
+        if P.one_batch:
+            out = self._run_model(rows, t_dev, text, pooled, None if cond is None else cond[K], self._cn_scale)
+            g_out, v_out = out[:n_g], out[n_g:]
+        else:
+            g_out = self._run_model(g_rows, t_dev, text[:n_g], pooled[:n_g],
+                                    None if cond is None else cond[K][0], self._cn_scale)
+            v_out = self._run_model(v_rows, t_dev, text[n_g:], pooled[n_g:],
+                                    None if cond is None else cond[K][1], self._cn_scale)
+        dirs = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
+        uncond_last = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
+        ops.unpad_direction(g_out, dirs, uncond_last, P.gpad.top, P.gpad.left)
+        direction = torch.empty_like(x)
+        low_dir = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
+        ops.fill_directions(dirs, idx, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction, low_dir)
+        local = torch.empty_like(x)
+        ops.scatter_centres(v_out, local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src)
+        prev, x0 = torch.empty_like(x), torch.empty_like(x)
+        ops.cfg_ddim_step(local, direction, x, prev, x0, np.float32(g), *self._step_coef[ti])
+        info = {"low_latent": low[K - 1], "uncond_score": uncond_last, "low_direction": low_dir,
+                "direction": direction, "local": local, "init_low": low[0]}
+        return prev, x0, info
+
+    def _undo(self, x, ti_next):
+        """ED:692-704; noise drawn on the host generator in the reference's order, staged through pinned memory."""
+        n_sub = self._undo_coef.shape[1]
+        host = self._stager.host((n_sub,) + tuple(x.shape), torch.float32)
+        host_rng.draw_noise_into(host)
+        noise = self._stager.upload(host, self.device)
+        out = torch.empty_like(x)
+        ops.undo_step(x, noise, self._undo_coef[ti_next], out)
+        return out
+
+    # ---- ControlNet condition rows (EDC:457-461, 932-949) -- constant over the whole image ------------
+    def _condition_rows(self, P, cond_img, B, Ks):
+        s = self.vae_scale_factor
+        cond_img = cond_img.to(self.device, torch.float32).contiguous()
+        assert cond_img.shape[0] == 1 and tuple(cond_img.shape[-2:]) == (P.h * s, P.w * s), \
+            "condition image must be (1,3,8h,8w) at the reduced resolution (EDC:1183-1193)"
+        mdt = next(self.controlnet.parameters()).dtype
+        # global rows: zero pad in pixel space
+        gp = P.gpad
+        rows_g = np.full((1, gp.PH * s), -1, dtype=np.int32)
+        cols_g = np.full((1, gp.PW * s), -1, dtype=np.int32)
+        rows_g[0, gp.top * s:(gp.top + P.h) * s] = np.arange(P.h * s)
+        cols_g[0, gp.left * s:(gp.left + P.w) * s] = np.arange(P.w * s)
+        g_img = torch.empty(1, 3, gp.PH * s, gp.PW * s, device=self.device, dtype=mdt)
+        ops.gather2d(cond_img, g_img, self._dev_i32([0]), self._dev_i32(rows_g), self._dev_i32(cols_g))
+        # view rows: nearest upsample to full resolution (index map), crop per view at pixel scale, zero pad
+        up_r = geometry.nearest_index_map(P.h * s, P.Hl * s)
+        up_c = geometry.nearest_index_map(P.w * s, P.Wl * s)
+        vp, V = P.vpad, P.views.V
+        n = (self.view_config["context_size"] * 8) // 2
+        rows_v = np.full((V, vp.PH * s), -1, dtype=np.int32)
+        cols_v = np.full((V, vp.PW * s), -1, dtype=np.int32)
+        for v, (h0, h1, w0, w1) in enumerate(P.views.views):
+            bt, at = geometry.axis_context(h0 * 8, h1 * 8, P.Hl * s, n)
+            bl, al = geometry.axis_context(w0 * 8, w1 * 8, P.Wl * s, n)
+            rr = up_r[h0 * 8 - bt: h1 * 8 + at]
+            cc = up_c[w0 * 8 - bl: w1 * 8 + al]
+            rows_v[v, vp.top * s: vp.top * s + len(rr)] = rr
+            cols_v[v, vp.left * s: vp.left * s + len(cc)] = cc
+        v_img = torch.empty(V, 3, vp.PH * s, vp.PW * s, device=self.device, dtype=mdt)
+        ops.gather2d(cond_img, v_img, self._dev_i32([0] * V), self._dev_i32(rows_v), self._dev_i32(cols_v))
+        out = {}
+        for K in Ks:
+            g_part = g_img.expand(2 * K * B, -1, -1, -1)
+            v_part = v_img.repeat_interleave(B, dim=0)
+            out[K] = torch.cat([g_part, v_part]).contiguous() if P.one_batch else (g_part.contiguous(), v_part.contiguous())
+        return out
+
+    # ---- the loop (ED:953-1078) --------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_latents(self, prompts, negative_prompts="", height=768, width=768, num_inference_steps=50,
+                         guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
+                         rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
+                         progress=_identity_progress, condition_image=None, controlnet_conditioning_scale=1.0,
+                         trace=None):
+        P = self._plan(height, width)
+        self.default_size = (4 * height, 4 * width)  # ED:969
+        n_rrg = num_inference_steps - int(num_inference_steps * rrg_stop_t)
+        if rrg_scherduler_cls is CosineScheduler or getattr(rrg_scherduler_cls, "__name__", "") == "CosineScheduler":
+            rrg = rrg_scherduler_cls(steps=n_rrg, cosine_scale=cosine_scale, factor=rrg_init_weight)
+        else:
+            rrg = rrg_scherduler_cls(steps=n_rrg, start_val=rrg_init_weight, stop_val=0)
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        if isinstance(negative_prompts, str):
+            negative_prompts = [negative_prompts] * len(prompts)
+        un, pun = self.get_text_embeds(negative_prompts)
+        co, pco = self.get_text_embeds(prompts)
+        B, C = len(prompts), self.unet.config.in_channels
+        dev = self.device
+        # initial latent from the host generator (ED:998-1000), then the schedule
+        x_host = self._stager.host((B, C, P.Hl, P.Wl), torch.float32)
+        x_host.normal_()
+        x = self._stager.upload(x_host, dev)
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        T = len(ts)
+        self._timesteps = list(ts)
+        self._t_dev = ts.to(dev)
+        self._step_coef = [self.scheduler.step_coefficients(t) for t in ts]
+        R = resampling_steps
+        repaint = bool(repaint_sampling) and R > 0
+        if repaint:
+            self._undo_coef = torch.stack([self.scheduler.undo_coefficients(t) for t in ts]).to(dev)
+        d0, d1 = self.default_size
+        self._time_ids = torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32, device=dev)  # ED:232-246, 414-418
+        self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
+        self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
+        Ks = sorted({R + 1, 1} if repaint else {R + 1})
+        emb = {K: self._embed_rows(K, P.views.V, un, co, pun, pco) for K in Ks}
+        cond = None
+        self._cn_scale = controlnet_conditioning_scale
+        if condition_image is not None:
+            if self.controlnet is None:
+                raise ValueError("condition_image given but no controlnet was supplied")
+            cond = self._condition_rows(P, condition_image, B, Ks)
+        norm = np.float32(2.0 / (C * P.Hl * P.Wl))
+        for i, t in enumerate(progress(self._timesteps)):
+            prev, x0, info = self._phase(P, x, i, R + 1, guidance_scale, 1 - new_p, emb, cond)
+            cfg = guidance_scale
+            if repaint and i < T - 1:  # ED:1038-1056
+                x = self._undo(prev, i + 1)
+                cfg = guidance_scale / 3
+                prev, x0, info = self._phase(P, x, i, 1, cfg, 1 - new_p, emb, cond)
+            w_i = rrg(i)
+            if w_i > 10:  # ED:1061-1078
+                sb, sa = self._step_coef[i][0], self._step_coef[i][1]
+                nxt = torch.empty_like(prev)
+                ops.rrg_update(prev, x0, info["low_latent"], info["uncond_score"], info["low_direction"], P.up_row,
+                               P.up_col, nxt, np.float32(cfg), sb, sa, norm, np.float32(w_i))
+                x = nxt
+            else:
+                x = prev
+            if trace is not None:
+                trace.append(x.clone())
+        self.last_latents = x
+        return x
+
+    # ---- decode (ED:267-310) -----------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_latents(self, latents):
+        vdt = next(self.vae.parameters()).dtype
+        img = self.vae.decode((latents / self.vae.config.scaling_factor).to(vdt)).sample
+        return (img.float() / 2 + 0.5).clamp(0, 1)
+
+    @torch.no_grad()
+    def tiled_decode(self, latents, tile_batch=8):
+        """ED:275-310 with the tiles gathered in one launch, decoded ``tile_batch`` at a time (and sharded over ranks),
+        and accumulated + normalised in one launch."""
+        B, C, Hl, Wl = latents.shape
+        s = self.vae_scale_factor
+        tp = geometry.TilePlan(Hl, Wl, self.unet.config.sample_size, s, low_vram=self.low_vram)
+        vdt = next(self.vae.parameters()).dtype
+        tiles = torch.empty(tp.T * B, C, tp.Ts, tp.Ts, device=self.device, dtype=vdt)
+        ops.tile_gather_pad(latents.contiguous(), tiles, self._dev_i32(tp.tile_y0), self._dev_i32(tp.tile_x0),
+                            self.vae.config.scaling_factor)
+
+        def dec(rows, *_):
+            outs = [self.vae.decode(rows[a:a + tile_batch]).sample for a in range(0, rows.shape[0], tile_batch)]
+            return torch.cat(outs).contiguous()
+
+        decoded = self.sharder.run(dec, tiles, None, None, None)
+        image = torch.empty(B, decoded.shape[1], Hl * s, Wl * s, device=self.device, dtype=torch.float32)
+        rt, rs, ct, cs = tp.pixel_tables()
+        ops.tile_accumulate_normalise(decoded, image, tp.n_col_tiles, self._dev_i32(rt), self._dev_i32(rs),
+                                      self._dev_i32(ct), self._dev_i32(cs))
+        return image
+
+    @torch.no_grad()
+    def generate_image(self, prompts, negative_prompts="", height=768, width=768, num_inference_steps=50,
+                       guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
+                       rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
+                       progress=_identity_progress, tiled_decoder=False, grid=False, *, condition_image=None,
+                       controlnet_conditioning_scale=1.0, output_type="pil"):
+        """ED:953-965 signature (ControlNet keywords of EDC:1120-1134 are keyword-only here).
+        Returns ``(images, image_log)``; images are PIL by default, a float tensor with ``output_type='pt'``."""
+        z = self.generate_latents(prompts, negative_prompts, height, width, num_inference_steps, guidance_scale,
+                                  resampling_steps, new_p, rrg_stop_t, rrg_init_weight, rrg_scherduler_cls,
+                                  cosine_scale, repaint_sampling, progress, condition_image,
+                                  controlnet_conditioning_scale)
+        dec = self.tiled_decode if tiled_decoder else self.decode_latents
+        imgs = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])  # decode_bs = 1 (ED:1090, 1121)
+        if grid:
+            imgs = torch.cat(list(imgs), dim=-1)[None]  # make_grid(nrows=len) without padding lines
+        if output_type == "pt":
+            return imgs, {}
+        from PIL import Image
+        arr = imgs.mul(255).byte().permute(0, 2, 3, 1).cpu().numpy()  # what ToPILImage does for float CHW (ED:1125)
+        return [Image.fromarray(a) for a in arr], {}

@@ -1,0 +1,176 @@
+/*
+ * elastic_hip.h -- C ABI of libelastic_hip.so: the MI355X (gfx950) kernels behind the patched global/local
+ * denoising loop of ElasticDiffusion.generate_image().
+ *
+ * The reference (MoayedHajiAli/ElasticDiffusion-official) is pure Python and has NO FFI / plugin boundary; its glue
+ * is eager torch ops inside /root/reference/elastic_diffusion.py ("ED:n" below) and
+ * /root/reference/elastic_diffusion_w_controlnet.py ("EDC:n").  Each entry point names the reference lines it
+ * replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - return value: hipError_t as int (0 == hipSuccess); never throws, never allocates, never synchronises;
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors), NCHW contiguous unless stated;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); NULL = default stream;
+ *   - "dtype" arguments: ED_F32 / ED_F16 / ED_BF16 select the element type of the buffer crossing the torch model
+ *     boundary (UNet / VAE / ControlNet tensors).  All latent-space state is fp32;
+ *   - arithmetic is fp32 with contraction disabled, in the operation order of the reference's torch-CPU path, so
+ *     results are bit-identical to it for fp32 model tensors;
+ *   - re-entrant, stateless; one host thread per process, one process per GPU.
+ */
+#ifndef ELASTIC_HIP_H
+#define ELASTIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ED_F32 = 0, ED_F16 = 1, ED_BF16 = 2 };
+
+/* ABI version, bumped on any signature change. */
+int ed_version(void);
+
+/* Name of the last HIP error code (hipGetErrorString), for the Python wrapper's RuntimeError. */
+const char* ed_error_string(int err);
+
+/*
+ * ed_gather_views -- ED:706-757 crop_with_context (S == 1: one contiguous window per view) + ED:845 cat, and the
+ * pad-to-model-size of ED:404-411 when a view is smaller than the UNet's native size.
+ *   latent  f32 [B,C,H,W]
+ *   out     dtype [(V*B),C,PH,PW]   row = v*B + b
+ *   win_y0/win_x0  int32[V]  window origin in the latent (context included); windows are Sh x Sw
+ *   (off_y,off_x)  where the window lands inside the PH x PW row; outside it the row is `frame` (f32 [C,PH,PW],
+ *                  the noised-background strips of ED:366-391) or 0 when frame == NULL
+ *   Source positions outside the latent read 0 (used by ed_tile_gather_pad).  divisor != 1 divides every value
+ *   taken from the latent (IEEE division).
+ */
+int ed_gather_views(const float* latent, void* out, int dtype, int B, int C, int H, int W,
+                    const int32_t* win_y0, const int32_t* win_x0, int V, int Sh, int Sw,
+                    int PH, int PW, int off_y, int off_x, const float* frame, float divisor, void* stream);
+
+/*
+ * ed_scatter_centres -- ED:852-861: write each view's centre into the full-resolution buffer where it is still
+ * exactly 0, in view order (first writer wins, decided by VALUE like the reference's `!= 0` mask).
+ * Implemented as a gather per destination pixel over the (<= 2 x 2) views whose centre covers it, ascending view
+ * index, stop at the first value != 0; no read-modify-write, `local` need not be zeroed.
+ *   pred    dtype [(V*B),C,PH,PW]  UNet output rows, row = v*B + b, view v = rb*n_col_blocks + cb
+ *   local   f32 [B,C,H,W]
+ *   row_blk int32[H*2]  the row-blocks rb whose centre covers latent row Y (ascending, -1 = none)
+ *   row_src int32[H*2]  the row inside the PH x PW prediction that holds latent row Y for that block
+ *   col_blk / col_src   same for columns
+ */
+int ed_scatter_centres(const void* pred, int dtype, float* local, int B, int C, int H, int W,
+                       int PH, int PW, int n_col_blocks,
+                       const int32_t* row_blk, const int32_t* row_src,
+                       const int32_t* col_blk, const int32_t* col_src, void* stream);
+
+/*
+ * ed_pick_assemble -- ED:560-630 random_nearest_downsample (value path) + ED:436 cat([latent]*2) + ED:404-411
+ * background_pad, for K resampling steps at once.  The random choice itself stays on the host (torch CPU
+ * generator, parity): idx holds one pick in [0,4) per reduced pixel and step.
+ *   latent  f32 [B,C,H,W]
+ *   idx     uint8 [K, h*w]
+ *   src_row int32[2h] / src_col int32[2w]  latent row/col behind each line of the 2h x 2w pick grid (ED:565-613)
+ *   frame   f32 [C,PH,PW] or NULL; the reduced latent sits at (off_y,off_x) inside the PH x PW model input
+ *   out     dtype [(K*2*B),C,PH,PW]  row = (k*2 + j)*B + b, j = 0 uncond copy, 1 cond copy
+ *   low     f32 [K,B,C,h,w] or NULL  the picked reduced-resolution latents (ED:678, 686)
+ */
+int ed_pick_assemble(const float* latent, const uint8_t* idx, const int32_t* src_row, const int32_t* src_col,
+                     const float* frame, void* out, int dtype, float* low,
+                     int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x,
+                     void* stream);
+
+/*
+ * ed_unpad_direction -- ED:429-430 crop padding + ED:439-440 chunk(2), direction = cond - uncond, for K steps.
+ *   unet_out dtype [(K*2*B),C,PH,PW]  rows as written by ed_pick_assemble
+ *   dirs     f32 [K,B,C,h,w]
+ *   uncond_last f32 [B,C,h,w] or NULL: uncond score of step K-1 (ED:687)
+ */
+int ed_unpad_direction(const void* unet_out, int dtype, float* dirs, float* uncond_last,
+                       int K, int B, int C, int h, int w, int PH, int PW, int off_y, int off_x, void* stream);
+
+/*
+ * ed_fill_directions -- ED:633-647 fill_in_from_downsampled_direction applied for K steps in order + ED:688.
+ * Per full-resolution pixel: the LAST step whose pick mask covers it supplies the value; if none, step K-1
+ * (fill_all).  Value = nearest-upsampled direction of that step at the pixel.
+ *   dirs    f32 [K,B,C,h,w];  idx uint8 [K,h*w]
+ *   inv_row int32[H*2] / inv_col int32[W*2]  lines of the 2h x 2w pick grid that fold onto latent row/col
+ *                                            (ED:446-465 restore_mask_shape, ED:622-628), -1 = none
+ *   up_row int32[H] / up_col int32[W]        F.interpolate(nearest) source index reduced<-full (ED:636)
+ *   down_row int32[h] / down_col int32[w]    F.interpolate(nearest) source index full<-reduced (ED:688)
+ *   target  f32 [B,C,H,W];  low_dir f32 [B,C,h,w] or NULL
+ */
+int ed_fill_directions(const float* dirs, const uint8_t* idx,
+                       const int32_t* inv_row, const int32_t* inv_col,
+                       const int32_t* up_row, const int32_t* up_col,
+                       const int32_t* down_row, const int32_t* down_col,
+                       float* target, float* low_dir,
+                       int K, int B, int C, int H, int W, int h, int w, void* stream);
+
+/*
+ * ed_cfg_ddim_step -- ED:1031/1053 noise = local + g * direction, then diffusers DDIMScheduler.step (eta = 0,
+ * epsilon prediction; call sites ED:1033, 1054):
+ *   x0   = (x - sqrt_beta_t * noise) / sqrt_alpha_t
+ *   prev = sqrt_alpha_prev * x0 + sqrt_one_minus_alpha_prev * noise
+ * All buffers f32 [n]; coefficient scalars are computed on the host in fp32 exactly like diffusers does.
+ */
+int ed_cfg_ddim_step(const float* local, const float* direction, const float* x, float* prev, float* x0,
+                     float g, float sqrt_beta_t, float sqrt_alpha_t, float sqrt_alpha_prev,
+                     float sqrt_one_minus_alpha_prev, int64_t n, void* stream);
+
+/*
+ * ed_undo_step -- ED:692-704 RePaint re-noising: n_sub sequential x <- a_k * x + b_k * noise_k in registers.
+ *   noise f32 [n_sub, n] (drawn on the host generator, parity);  coef f32 [n_sub,2] = (sqrt(1-beta), sqrt(beta))
+ */
+int ed_undo_step(const float* x_in, const float* noise, const float* coef, float* x_out,
+                 int n_sub, int64_t n, void* stream);
+
+/*
+ * ed_rrg_update -- ED:885-940 reduced_resolution_guidance on cached low-res scores + ED:1078:
+ *   eps_low = low_uncond + g * low_dir;  x0_low = (low_latent - sqrt_beta_t * eps_low) / sqrt_alpha_t
+ *   up      = nearest-upsample(x0_low);  out = prev - ((norm * (x0 - up)) * weight)
+ * which is the closed form of the reference's autograd of weight * mse_loss(up, x0) w.r.t. x0 (norm = 2/numel of
+ * ONE sample, ED:927-936).  Full-res buffers f32 [B,C,H,W], low-res f32 [B,C,h,w].
+ */
+int ed_rrg_update(const float* prev, const float* x0, const float* low_latent, const float* low_uncond,
+                  const float* low_dir, const int32_t* up_row, const int32_t* up_col, float* out,
+                  float g, float sqrt_beta_t, float sqrt_alpha_t, float norm, float weight,
+                  int B, int C, int H, int W, int h, int w, void* stream);
+
+/*
+ * ed_gather2d -- generic table-driven 2-D gather used for ED:868-883 nearest_interpolate, the ControlNet
+ * condition handling (EDC:457-461 zero pad, EDC:932-949 upsample + per-view crop) and debugging:
+ *   out[n,c,i,j] = (rows[n,i] < 0 || cols[n,j] < 0) ? 0 : in[src_n[n], c, rows[n,i], cols[n,j]]
+ *   in  in_dtype [Bin,C,H,W];  out out_dtype [N,C,oh,ow];  rows int32[N,oh];  cols int32[N,ow];  src_n int32[N]
+ */
+int ed_gather2d(const void* in, int in_dtype, void* out, int out_dtype, int C, int H, int W,
+                const int32_t* src_n, const int32_t* rows, const int32_t* cols, int N, int oh, int ow, void* stream);
+
+/*
+ * ed_tile_gather_pad -- ED:287-300: tiles of the zero-padded latent for the tiled VAE decode, already divided by
+ * the VAE scaling factor (ED:269).  Same kernel as ed_gather_views with out-of-range reads = 0.
+ *   latent f32 [B,C,H,W] -> tiles dtype [(T*B),C,Ts,Ts], tile origin (tile_y0[t]-pad, tile_x0[t]-pad)
+ */
+int ed_tile_gather_pad(const float* latent, void* tiles, int dtype, int B, int C, int H, int W,
+                       const int32_t* tile_y0, const int32_t* tile_x0, int T, int Ts, float scaling_factor,
+                       void* stream);
+
+/*
+ * ed_tile_accumulate_normalise -- ED:271 (img/2 + 0.5).clamp(0,1) per tile, ED:303-308 image += centre;
+ * count += 1; image / count.  Gather form: per output pixel, sum the covering tiles in ascending tile order.
+ *   decoded dtype [(T*B),Cimg,TP,TP] raw VAE output (TP = Ts*scale), row = t*B + b, tile t = rb*n_col_tiles + cb
+ *   image   f32 [B,Cimg,HP,WP]
+ *   row_tile int32[HP*MAXC] / row_src int32[HP*MAXC]: tiles (row index rb, ascending, -1 = none) covering pixel
+ *   row Y and the row inside the decoded tile; same for columns.  MAXC = ED_TILE_MAXC.
+ */
+#define ED_TILE_MAXC 4
+int ed_tile_accumulate_normalise(const void* decoded, int dtype, float* image, int B, int Cimg, int HP, int WP,
+                                 int TP, int n_col_tiles,
+                                 const int32_t* row_tile, const int32_t* row_src,
+                                 const int32_t* col_tile, const int32_t* col_src, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELASTIC_HIP_H */

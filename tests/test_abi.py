@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/elastic_hip.h declares
+(no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+from elasticdiffusion_official_amd import _hip
+
+
+def header_functions():
+    text = open(os.path.join(_hip.INCLUDE, "elastic_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.findall(r"\b(?:int|const char\*)\s+(ed_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _hip.build_library()
+    L = _hip.lib()
+    declared = header_functions()
+    names = [n for n, _ in declared]
+    assert len(names) >= 13 and len(set(names)) == len(names)
+    assert set(names) == set(_hip.SIGNATURES), "header and ctypes signature table disagree"
+    for name, args in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+        n_args = 0 if args.strip() in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        assert n_args == len(_hip.SIGNATURES[name]), f"{name}: header has {n_args} args, ctypes table {len(_hip.SIGNATURES[name])}"
+    assert L.ed_version() == _hip.ABI_VERSION
+    assert L.ed_error_string(0)
+
+
+def test_product_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from elasticdiffusion_official_amd import ElasticDiffusion, ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ElasticDiffusion(torch.device("cpu"), "1.5")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cfg_ddim_step(*(torch.zeros(8) for _ in range(5)), 1.0, 1.0, 1.0, 1.0, 1.0)
+
+
+def test_package_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import elasticdiffusion_official_amd as p; from elasticdiffusion_official_amd import pipeline, ops, "
+            "geometry, host_rng, schedule, sharding; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=_hip.ROOT_DIR)

@@ -1,0 +1,188 @@
+"""CPU: the product's host-side logic (integer tables, RNG replay, schedule scalars) against the oracle and the
+golden fixtures written by the real reference.  Everything here is integer / index work or scalar fp32: exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from elasticdiffusion_official_amd import geometry, host_rng, schedule
+from oracle import elastic_oracle as eo
+from oracle.ddim import DDIMOracle
+from tests.fakes import FakeUNet, FakeVAE
+from tests.golden import cases
+
+
+def test_view_plan_matches_reference_views_and_crops(golden_dir):
+    rows = json.load(open(os.path.join(golden_dir, "g1_views.json")))
+    for r in rows:
+        H, W, sample, patch = r["H"], r["W"], r["sample"], r["patch"]
+        ws = patch if patch is not None else sample // 2
+        vp = geometry.ViewPlan(H // 8, W // 8, ws, ws, sample - ws)
+        assert [list(v) for v in vp.views] == r["views"]
+        assert [list(c) for c in vp.ctx] == [c["n4"] for c in r["crops"]]
+        Wl = W // 8
+        for v in range(vp.V):  # contiguous window: first / last element of an index image
+            assert [vp.Sh, vp.Sw] == r["crops"][v]["shape"]
+            assert int(vp.win_y0[v]) * Wl + int(vp.win_x0[v]) == r["crops"][v]["first"]
+            assert (int(vp.win_y0[v]) + vp.Sh - 1) * Wl + int(vp.win_x0[v]) + vp.Sw - 1 == r["crops"][v]["last"]
+        assert list(geometry.reduced_size(H, W, "1.5")) == r["downsample_sd"]
+        assert list(geometry.reduced_size(H, W, "XL1.0")) == r["downsample_xl"]
+
+
+def test_cover_tables_reproduce_first_writer_wins():
+    for (Hl, Wl, ws, ctx) in [(67, 97, 32, 32), (135, 240, 32, 32), (128, 256, 64, 64), (96, 96, 48, 16)]:
+        vp = geometry.ViewPlan(Hl, Wl, ws, ws, ctx)
+        rb, rs, cb, cs = vp.cover_tables()
+        owner = np.full((Hl, Wl), -1)
+        for k, (h0, h1, w0, w1) in reversed(list(enumerate(vp.views))):
+            owner[h0:h1, w0:w1] = k  # lowest index wins
+        got = rb.reshape(Hl, 2)[:, 0][:, None] * vp.n_col_blocks + cb.reshape(Wl, 2)[:, 0][None, :]
+        np.testing.assert_array_equal(got, owner)
+
+
+@pytest.mark.parametrize("name", list(cases.G2_CASES))
+def test_pick_plan_matches_reference_tables_and_masks(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "g2_downsample.npz"))
+    Hl, Wl, h, w, seed = cases.G2_CASES[name]
+    try:
+        pp = geometry.PickPlan(Hl, Wl, h, w)
+    except ValueError:
+        assert name == "r65_97"  # mask folds to 67 lines > 65: the reference's fill raises for this size too
+        return
+    nr, nc = len(g[f"{name}/table_row_indices"]), len(g[f"{name}/table_col_indices"])
+    np.testing.assert_array_equal(pp.src_row[:nr], g[f"{name}/table_row_indices"] // 2)
+    np.testing.assert_array_equal(pp.src_col[:nc], g[f"{name}/table_col_indices"] // 2)
+    torch.manual_seed(seed)
+    x = torch.randn(1, 4, Hl, Wl)
+    for step in range(3):
+        idx = g[f"{name}/idx{step}"].astype(np.int64).reshape(h, w)
+        ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        low = x[0, :, pp.src_row[2 * ii + idx // 2], pp.src_col[2 * jj + idx % 2]]
+        np.testing.assert_array_equal(low.numpy(), g[f"{name}/low{step}"][0])
+        shape = tuple(g[f"{name}/mask_shape{step}"])
+        want = np.unpackbits(g[f"{name}/mask{step}"])[: shape[0] * shape[1]].reshape(shape).astype(bool)
+        mask = np.zeros((Hl, Wl), dtype=bool)
+        inv_r, inv_c = pp.inv_row.reshape(Hl, 2), pp.inv_col.reshape(Wl, 2)
+        for Y in range(Hl):
+            for X in range(Wl):
+                for r in inv_r[Y]:
+                    for c in inv_c[X]:
+                        if r >= 0 and c >= 0 and idx[r // 2, c // 2] == (r % 2) * 2 + (c % 2):
+                            mask[Y, X] = True
+        np.testing.assert_array_equal(mask, want)
+
+
+def test_nearest_index_maps_are_torch_nearest():
+    for n_in, n_out in [(36, 135), (64, 240), (135, 36), (44, 67), (97, 64), (128, 256), (7, 5)]:
+        m = geometry.nearest_index_map(n_in, n_out)
+        x = torch.randn(1, 1, n_in, 3)
+        np.testing.assert_array_equal(F.interpolate(x, size=(n_out, 3), mode="nearest").numpy(), x[:, :, m].numpy())
+
+
+def test_pad_plan_strip_order_and_sizes():
+    p = geometry.PadPlan(32, 64, 64)
+    assert (p.PH, p.PW, p.top, p.bottom, p.left, p.right) == (64, 64, 16, 16, 0, 0)
+    assert [(s[0], s[1], s[2], s[3]) for s in p.strips] == [(2, 1, 16, 64), (2, 2, 16, 64)]
+    q = geometry.PadPlan(33, 50, 64)  # both axes, odd split
+    assert (q.top, q.bottom, q.left, q.right) == (15, 16, 7, 7)
+    assert [(s[0], s[1], s[2], s[3]) for s in q.strips] == [(3, 1, 33, 7), (3, 2, 33, 7), (2, 1, 15, 64), (2, 2, 16, 64)]
+    assert not geometry.PadPlan(64, 64, 64).padded
+
+
+def test_strip_draws_and_reseed_replay_match_reference_side_effects():
+    """make_denoised_background through the oracle vs the product's private-generator draws + replay."""
+    orc = eo.ElasticOracle(FakeUNet(64), FakeVAE(), DDIMOracle())
+    orc.scheduler.set_timesteps(50)
+    t = orc.scheduler.timesteps[4]
+    host_rng.seed_everything(3)
+    want = orc.make_denoised_background((16, 64), t, "2_1")
+    tail_t, tail_n = torch.rand(3), np.random.randint(1000)
+    host_rng.seed_everything(3)
+    colour, post, fwd = host_rng.strip_draws(2, 1, 16, 64, t)
+    host_rng.replay_strip_reseeds(1)
+    assert torch.equal(torch.rand(3), tail_t) and np.random.randint(1000) == tail_n
+    vae = FakeVAE()
+    dist = vae.encode(colour[:, :, None, None].repeat(1, 1, 128, 512)).latent_dist
+    enc = (dist.mean + dist.std * post) * vae.config.scaling_factor
+    sa, so = schedule.DDIMSchedule().add_noise_coefficients(t)
+    assert torch.equal(np.float32(sa) * enc + np.float32(so) * fwd, want)
+
+
+def test_pick_sampler_replays_reference_rng_trace(golden_dir):
+    """Full host-side replay for cfg2: same (fn, shape) event sequence as the reference run."""
+    from tests.golden.make_golden import RngTrace
+    want = json.load(open(os.path.join(golden_dir, "g9_rng_trace.json")))["cfg2_sd_512x1024"]
+    # events the product draws on the global generators: everything except the md5-seeded strip internals
+    skip = 0
+    filtered = []
+    for ev in want:
+        if skip:
+            skip -= 1
+            continue
+        if ev[0] == "manual_seed" and filtered and filtered[-1][0] != "np_randint":
+            skip = 3  # rand(1,3), randn (posterior), randn_like inside the md5-seeded section
+            continue
+        filtered.append(ev)
+    c = cases.E2E_CASES["cfg2_sd_512x1024"]
+    pp = geometry.PickPlan(64, 128, 32, 64)
+    gpad = geometry.PadPlan(32, 64, 64)
+    sampler = host_rng.PickSampler(pp.N)
+    sch = schedule.DDIMSchedule()
+    ts = sch.set_timesteps(c["steps"])
+    host_rng.seed_everything(c["seed"])
+    with RngTrace() as tr:
+        torch.randn(1, 4, 64, 128)
+        for i in range(len(ts)):
+            sampler.draw(c["R"] + 1, 0.7, lambda: host_rng.replay_strip_reseeds(len(gpad.strips)))
+            if i < len(ts) - 1:
+                for _ in range(1000 // c["steps"]):
+                    torch.randn(1, 4, 64, 128)
+                sampler.draw(1, 0.7, lambda: host_rng.replay_strip_reseeds(len(gpad.strips)))
+    got = [e for e in tr.events]
+    assert got == filtered
+
+
+@pytest.mark.parametrize("steps", [50, 10, 4, 20])
+def test_schedule_scalars_match_oracle_ddim(steps):
+    sch, orc = schedule.DDIMSchedule(), DDIMOracle()
+    ts = sch.set_timesteps(steps)
+    orc.set_timesteps(steps)
+    assert torch.equal(ts, orc.timesteps) and str(ts[0]) == f"tensor({int(ts[0])})"
+    x, e = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    for t in ts:
+        sb, sa, sp, sd = (np.float32(v) for v in sch.step_coefficients(t))
+        out = orc.step(e, t, x)
+        x0 = (x - sb * e) / sa
+        assert torch.equal(x0, out["pred_original_sample"])
+        assert torch.equal(sp * x0 + sd * e, out["prev_sample"])
+    coef = sch.undo_coefficients(ts[1])
+    assert coef.shape == (1000 // steps, 2)
+    b = orc.betas[int(ts[1])]
+    assert coef[0, 0] == (1 - b) ** 0.5 and coef[0, 1] == b ** 0.5
+
+
+def test_rrg_schedulers_match_oracle():
+    for i in range(60):
+        assert schedule.CosineScheduler(40, 10.0, 1000)(i) == eo.CosineScheduler(40, 10.0, 1000)(i)
+        assert schedule.LinearScheduler(40, 1000, 0)(i) == eo.LinearScheduler(40, 1000, 0)(i)
+        assert schedule.ConstScheduler(40, 1000, 0)(i) == eo.ConstScheduler(40, 1000, 0)(i)
+
+
+def test_tile_plan_matches_reference_tiling():
+    for (Hl, Wl, sample, low_vram) in [(16, 24, 32, False), (20, 28, 32, True), (256, 256, 128, False), (135, 240, 64, True)]:
+        tp = geometry.TilePlan(Hl, Wl, sample, 8, low_vram)
+        core = sample // 4
+        stride = core // 2 if low_vram else core
+        views = eo.get_views(Hl * 8, Wl * 8, core, core, stride)
+        assert len(views) == tp.T
+        pad = core if low_vram else sample // 8 * 3
+        assert [(int(y) + pad, int(x) + pad) for y, x in zip(tp.tile_y0, tp.tile_x0)] == [(v[0], v[2]) for v in views]
+        rt, rs, ct, cs = tp.pixel_tables()
+        count = np.zeros((Hl * 8, Wl * 8))
+        for (h0, h1, w0, w1) in views:
+            count[h0 * 8:h1 * 8, w0 * 8:w1 * 8] += 1
+        got = (rt.reshape(-1, 4) >= 0).sum(1)[:, None] * (ct.reshape(-1, 4) >= 0).sum(1)[None, :]
+        np.testing.assert_array_equal(got, count)
