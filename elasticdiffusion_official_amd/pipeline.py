@@ -359,7 +359,9 @@ class ElasticDiffusion(nn.Module):
         R = resampling_steps
         repaint = bool(repaint_sampling) and R > 0
         if repaint:
-            self._undo_coef = torch.stack([self.scheduler.undo_coefficients(t) for t in ts]).to(dev)
+            # undo_step is only ever entered with timesteps[i+1] (ED:1040): row 0 is a placeholder
+            rows = [self.scheduler.undo_coefficients(t) for t in ts[1:]]
+            self._undo_coef = torch.stack(rows[:1] + rows).to(dev) if rows else None
         d0, d1 = self.default_size
         self._time_ids = torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32, device=dev)  # ED:232-246, 414-418
         self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
