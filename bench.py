@@ -1,0 +1,330 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: images/sec at 50 steps for SDXL H=1024 x W=2048 (configs[2]:
+view_batch_size=16, resampling_steps=7), plus per-view UNet ms, roofline figures and a CPU baseline.
+
+    python bench.py --gpus 1 --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = ONE full image through the hot path: generate_image() = 50 denoising timesteps of the patched
+global/local loop (1294 SDXL UNet forward-samples, ~8.75 PFLOP) + the VAE decode.  Inputs (text embeddings, weights)
+are resident in HBM when the timed region starts; data is synthetic (random-init SDXL-architecture weights from a
+fixed seed, synthetic text embeddings of CLIP shape) because no checkpoints/network exist in the build image.
+
+At N > 1 the rows of each fused model batch are sharded across ranks (one image, strong scaling); rank 0 prints the
+single JSON line.  See DESIGN.md "Measurement" for the algorithmic byte/FLOP figures used in "roofline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak
+
+WORKLOADS = {
+    # BASELINE.json configs[2] / README example (RM:54-73): the configuration the metric is quoted on
+    "sdxl_1024x2048": dict(sd="XL1.0", H=1024, W=2048, vbs=16, R=7, guidance=10.0, new_p=0.3, rrg_w=1000,
+                           cosine_scale=10.0, rrg_stop_t=0.2, tiled=False),
+    # configs[1]
+    "sd15_512x1024": dict(sd="1.5", H=512, W=1024, vbs=4, R=7, guidance=10.0, new_p=0.3, rrg_w=1000,
+                          cosine_scale=10.0, rrg_stop_t=0.2, tiled=False),
+    # configs[3]
+    "sdxl_2048x2048_tiled": dict(sd="XL1.0", H=2048, W=2048, vbs=16, R=7, guidance=10.0, new_p=0.3, rrg_w=4000,
+                                 cosine_scale=10.0, rrg_stop_t=0.2, tiled=True),
+}
+
+
+def forward_samples(T, R, V, repaint=True):
+    """UNet forward-samples per image: (T-1)[2(R+1)+V+(2+V)(R>0)] + [2(R+1)+V]."""
+    per = 2 * (R + 1) + V
+    rep = (2 + V) if (R > 0 and repaint) else 0
+    return (T - 1) * (per + rep) + per
+
+
+def unet_flops_per_sample(fam, dtype):
+    from torch.utils.flop_counter import FlopCounterMode
+    from elasticdiffusion_official_amd import models as M
+    cfg = M.UNET_CONFIGS[fam]
+    with torch.device("meta"):
+        u = M.UNet2DConditionModel(**cfg).to(dtype)
+        S = cfg["sample_size"]
+        x = torch.empty(1, 4, S, S, dtype=dtype)
+        e = torch.empty(1, 77, cfg["cross_attention_dim"], dtype=dtype)
+        kw = None
+        if cfg["pooled_projection_dim"]:
+            kw = {"text_embeds": torch.empty(1, cfg["pooled_projection_dim"], dtype=dtype), "time_ids": torch.empty(1, 6)}
+        with FlopCounterMode(display=False) as fc:
+            u(x, torch.empty((), dtype=torch.int64), encoder_hidden_states=e, added_cond_kwargs=kw)
+    return float(fc.get_total_flops())
+
+
+def algorithmic_bytes(name, wl_geo):
+    """ALGORITHMIC bytes per launch of each glue kernel (each logical tensor moved once), fp32 latents, model rows in
+    the model dtype (2 B).  L = full latent, l = reduced latent, row = one d x d model row.  DESIGN.md section 5."""
+    B, C, Hl, Wl, h, w, d, K, V, n_sub, mb = (wl_geo[k] for k in ("B", "C", "Hl", "Wl", "h", "w", "d", "K", "V", "n_sub", "mb"))
+    L, l, row = B * C * Hl * Wl * 4, B * C * h * w * 4, C * d * d * mb
+    return {
+        "ed_undo_step": (n_sub + 2) * L,
+        "ed_cfg_ddim_step": 5 * L,
+        "ed_rrg_update": 3 * L + 3 * l,
+        "ed_scatter_centres": V * B * row // 2 + L,           # centres are half of each crop on cfg3
+        "ed_gather_views": L + V * B * row,
+        # mean over the two call shapes (K = R+1 and K = 1) is reported by the caller using launches-weighted K
+        "ed_pick_assemble": lambda k: k * (l + h * w) + 2 * k * B * row + k * l,
+        "ed_unpad_direction": lambda k: 2 * k * B * row // 2 + k * l + l,
+        "ed_fill_directions": lambda k: k * l + k * h * w + L + l,
+    }[name]
+
+def kernel_replay(pipe, wl, T, reps=200):
+    """Mean duration of every glue kernel at the workload's launch shapes (phase-A shapes, K = R+1), measured with
+    HIP events on the launch stream around ``reps`` back-to-back launches (per-launch event pairs inside the image
+    loop are floored at ~10 us by event overhead, so they are reported separately as in_situ_us)."""
+    import numpy as np
+    from elasticdiffusion_official_amd import ops
+    dev = pipe.device
+    P = pipe._plan(wl["H"], wl["W"])
+    B, C, K, V = 1, 4, wl["R"] + 1, P.views.V
+    mdt = pipe.model_dtype
+    n_sub = 1000 // T
+    f32 = dict(device=dev, dtype=torch.float32)
+    x = torch.randn(B, C, P.Hl, P.Wl, **f32)
+    idx = torch.randint(0, 4, (K, P.pick.N), device=dev, dtype=torch.uint8)
+    rows = torch.empty(2 * K * B + V * B, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
+    frame = torch.randn(C, P.gpad.PH, P.gpad.PW, **f32) if P.gpad.padded else None
+    low = torch.empty(K, B, C, P.h, P.w, **f32)
+    out = torch.randn(rows.shape, **f32).to(mdt)
+    dirs, unc = torch.empty(K, B, C, P.h, P.w, **f32), torch.empty(B, C, P.h, P.w, **f32)
+    direction, low_dir, local = torch.empty_like(x), torch.empty(B, C, P.h, P.w, **f32), torch.empty_like(x)
+    prev, x0, nxt = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    noise = torch.randn(n_sub, B, C, P.Hl, P.Wl, **f32)
+    coef = torch.rand(n_sub, 2, **f32)
+    n_g = 2 * K * B
+    calls = {
+        "ed_pick_assemble": lambda: ops.pick_assemble(x, idx, P.src_row, P.src_col, rows[:n_g], P.h, P.w, P.gpad.top, P.gpad.left, frame, low),
+        "ed_gather_views": lambda: ops.gather_views(x, rows[n_g:], P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, None),
+        "ed_unpad_direction": lambda: ops.unpad_direction(out[:n_g], dirs, unc, P.gpad.top, P.gpad.left),
+        "ed_fill_directions": lambda: ops.fill_directions(dirs, idx, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction, low_dir),
+        "ed_scatter_centres": lambda: ops.scatter_centres(out[n_g:], local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src),
+        "ed_cfg_ddim_step": lambda: ops.cfg_ddim_step(local, direction, x, prev, x0, 10.0, 0.9, 0.4, 0.5, 0.8),
+        "ed_undo_step": lambda: ops.undo_step(prev, noise, coef, nxt),
+        "ed_rrg_update": lambda: ops.rrg_update(prev, x0, low[K - 1], unc, low_dir, P.up_row, P.up_col, nxt, 3.3, 0.9, 0.4, np.float32(2.0 / x.numel()), 800.0),
+    }
+    res = {}
+    for name, fn in calls.items():
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res[name] = 1e3 * a.elapsed_time(b) / reps
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed images")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up images")
+    ap.add_argument("--workload", default="sdxl_1024x2048", choices=list(WORKLOADS))
+    ap.add_argument("--timesteps", type=int, default=50, help="denoising steps per image (the metric is quoted at 50)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from elasticdiffusion_official_amd import ElasticDiffusion, models, ops
+
+    wl = WORKLOADS[args.workload]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    pipe = ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], model_dtype=dtype)
+    kw = dict(height=wl["H"], width=wl["W"], num_inference_steps=args.timesteps, guidance_scale=wl["guidance"],
+              resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"], rrg_init_weight=wl["rrg_w"],
+              cosine_scale=wl["cosine_scale"], repaint_sampling=True, tiled_decoder=wl["tiled"], output_type="pt")
+    prompt, negative = "An astronaut riding a corgi on the moon", "blurry, ugly, poorly drawn, deformed"
+
+    def one_image(seed):
+        pipe.seed_everything(seed)
+        imgs, _ = pipe.generate_image(prompt, negative, **kw)
+        return imgs
+
+    for i in range(args.warmup):
+        one_image(1000 + i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timing = (not args.no_kernel_timing)
+    fence()
+    if timing:
+        ops.TIMER.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        imgs = one_image(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ktimes = ops.TIMER.stop() if timing else {}
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(imgs).all())
+
+    if rank == 0:
+        fam = models.family(wl["sd"])
+        s = pipe.vae_scale_factor
+        Hl, Wl = wl["H"] // s, wl["W"] // s
+        h, w = pipe.get_downsample_size(wl["H"], wl["W"])
+        from elasticdiffusion_official_amd import geometry
+        vc = pipe.view_config
+        V = geometry.ViewPlan(Hl, Wl, vc["window_size"], vc["stride"], vc["context_size"]).V
+        T, R = args.timesteps, wl["R"]
+        fs = forward_samples(T, R, V)
+        flops_sample = unet_flops_per_sample(fam, dtype)
+        img_per_s = args.steps / elapsed
+        sec_per_img = elapsed / args.steps
+        e2e_tf = fs * flops_sample / sec_per_img / 1e12 / world
+        # per-view UNet ms: whole-image wall time / forward-samples is an upper bound that includes everything else
+        per_view_ms = 1e3 * sec_per_img * world / fs
+        geo = dict(B=1, C=4, Hl=Hl, Wl=Wl, h=h, w=w, d=pipe.model_size, K=R + 1, V=V, n_sub=1000 // T, mb=2)
+        kern = {}
+        replay = kernel_replay(pipe, wl, T) if timing else {}
+        for name, us in replay.items():
+            ab = algorithmic_bytes(name, geo)
+            if callable(ab):
+                ab = ab(R + 1)  # replay uses the phase-A launch shape (K = R+1)
+            n, in_situ, total_ms = ktimes.get(name, (0, None, 0.0))
+            kern[name] = dict(us_per_launch=round(us, 2), alg_bytes=int(ab), gbs=round(ab / (us * 1e-6) / 1e9, 1),
+                              launches_in_timed_region=n, in_situ_us=None if in_situ is None else round(in_situ, 2),
+                              est_total_ms=round(n * us * 1e-3, 3))
+        roof = None
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["est_total_ms"])
+            a = kern[dom]["gbs"]
+            roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                    "us_per_launch": kern[dom]["us_per_launch"],
+                    "note": "hand-written glue kernel with the largest total time in the timed region; duration = HIP "
+                            "events around 200 back-to-back launches at the workload's shapes; tensors are <= 11 MiB "
+                            "(L2/MALL resident, launch-latency bound); the end-to-end MFMA figure is roofline_e2e"}
+        out = {
+            "metric": "images/sec at 50 steps (SDXL 2048x1024)" if args.workload == "sdxl_1024x2048" and T == 50
+                      else f"images/sec at {T} steps ({args.workload})",
+            "value": round(img_per_s, 5), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_img, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": args.workload, "height": wl["H"], "width": wl["W"], "denoising_steps": T,
+                       "view_batch_size": wl["vbs"], "resampling_steps": R, "views": V, "prompts_per_image": 1,
+                       "unet_forward_samples_per_image": fs, "parallelism": f"row-shard x{world}",
+                       "weights": "random-init SDXL architecture (2.567 B params), seed 0", "vae_dtype": "fp32"},
+            "images_per_min": round(60 * img_per_s, 3),
+            "per_view_unet_ms": round(per_view_ms, 3),
+            "finite_output": finite,
+            "roofline": roof,
+            "roofline_e2e": {"bound": "mfma", "achieved": round(e2e_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(e2e_tf / MFMA_BF16_PEAK_TF, 4),
+                             "flops_per_forward_sample": flops_sample, "forward_samples": fs,
+                             "note": "UNet FLOPs only (VAE / glue excluded from the numerator), per GPU"},
+            "glue_kernels": kern,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pipe, wl, T, fs, V)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pipe, wl, T, fs, V):
+    """The oracle (kind "port": op-for-op CPU restatement of the reference, fixture-pinned) timed on the host cores on
+    a BOUNDED sample of the same workload: ONE fp32 UNet forward-sample at the model size on the CPU + the oracle glue
+    of ONE full timestep (zero-cost UNet), extrapolated to the image: fs * t_sample + T * t_glue (decode excluded).
+    Reported baseline, not the optimisation target."""
+    import copy
+    from oracle.ddim import DDIMOracle
+    from oracle.elastic_oracle import ElasticOracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    unet32 = copy.deepcopy(pipe.unet).to("cpu", torch.float32)
+    cfg = unet32.config
+    S = cfg.sample_size
+    x = torch.randn(1, 4, S, S)
+    e = torch.randn(1, 77, cfg.cross_attention_dim)
+    kw = None
+    if cfg.pooled_projection_dim:
+        kw = {"text_embeds": torch.randn(1, cfg.pooled_projection_dim), "time_ids": torch.zeros(1, 6)}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        unet32(x, torch.tensor(500), encoder_hidden_states=e, added_cond_kwargs=kw)
+        t_sample = time.perf_counter() - t0
+    del unet32
+
+    class ZeroCostUNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.add_embedding = type("A", (), {"linear_1": type("L", (), {"in_features": 0})()})()
+
+        def forward(self, x, t, **k):
+            return {"sample": x * 0.5}
+
+    class TinyVAE(torch.nn.Module):  # the pad-strip path calls vae.encode; give it an 8x8 average so it stays bounded
+        def __init__(self, vae):
+            super().__init__()
+            self.config = vae.config
+
+        def encode(self, img):
+            m = torch.nn.functional.avg_pool2d(img, 8).mean(1, keepdim=True).repeat(1, 8, 1, 1)
+            from elasticdiffusion_official_amd.models import DiagonalGaussian
+            return type("E", (), {"latent_dist": DiagonalGaussian(m)})()
+
+    emb = {"n": 0}
+    un, pun = pipe.get_text_embeds([""])
+    un, pun = un.cpu().float(), pun.cpu().float()
+
+    def embeds(_):
+        return un, pun
+
+    orc = ElasticOracle(ZeroCostUNet(), TinyVAE(pipe.vae), DDIMOracle(), embeds, sd_version=wl["sd"],
+                        view_batch_size=wl["vbs"])
+    orc.seed_everything(0)
+    t0 = time.perf_counter()
+    orc.generate_latent("p", "", height=wl["H"], width=wl["W"], num_inference_steps=T, guidance_scale=wl["guidance"],
+                        resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"],
+                        rrg_init_weight=wl["rrg_w"], cosine_scale=wl["cosine_scale"],
+                        progress=lambda ts: list(ts)[:1])
+    t_glue = time.perf_counter() - t0
+    sec_img = fs * t_sample + T * t_glue
+    return {"value": round(1.0 / sec_img, 8), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {fs} fp32 UNet forward-samples ({t_sample:.2f} s) + oracle glue of 1 of {T} timesteps "
+                      f"({t_glue:.2f} s, zero-cost UNet), extrapolated: {fs}*t_sample + {T}*t_glue = {sec_img:.0f} s/image; "
+                      "VAE decode excluded",
+            "t_forward_sample_s": round(t_sample, 3), "t_glue_step_s": round(t_glue, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,567 @@
+"""Torch-ROCm model modules behind the hot path's model boundary (``unet_step``, elastic_diffusion.py:393-432;
+``decode_latents`` :267-272; ``make_denoised_background`` :350; ControlNet elastic_diffusion_w_controlnet.py:476-518).
+
+The reference takes these from ``diffusers==0.21.4`` (``UNet2DConditionModel``, ``AutoencoderKL``,
+``ControlNetModel``), which is neither vendored nor installable here, and no pretrained weights exist offline.  These
+are from-scratch pure-torch modules with the SD-1.x / SD-2.x-base / SDXL-base architecture hyper-parameters and
+HF-layout parameter names (so a ``diffusion_pytorch_model.safetensors`` state dict loads with ``load_weights``).  For
+benchmarks they are randomly initialised from a fixed seed ("synthetic" in bench.py).
+
+This is plumbing, not the product: dense contractions (conv / linear / attention) go to MIOpen / hipBLASLt / SDPA,
+i.e. the MFMA pipes, through PyTorch-ROCm.  Layout choices that matter on MI355X: bf16 weights and activations,
+channels-last convolutions, fused QKV / KV projections, SDPA attention (64-wide heads for SDXL).
+"""
+import math
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ModelOutput(dict):
+    """``out['sample']`` and ``out.sample`` (the reference indexes the former, ED:422)."""
+
+    __getattr__ = dict.__getitem__
+
+
+# ---------------------------------------------------------------------------------------------------
+# shared blocks
+# ---------------------------------------------------------------------------------------------------
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000.0):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    sin, cos = torch.sin(emb), torch.cos(emb)
+    return torch.cat([cos, sin], dim=-1) if flip_sin_to_cos else torch.cat([sin, cos], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim=None, eps=1e-5, groups=32):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_dim, cout) if temb_dim else None
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x, temb=None):
+        h = self.conv1(F.silu(self.norm1(x)))
+        if self.time_emb_proj is not None:
+            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, head_dim, cross_dim=None, bias=False):
+        super().__init__()
+        inner = heads * head_dim
+        self.heads = heads
+        self.to_q = nn.Linear(dim, inner, bias=bias)
+        self.to_k = nn.Linear(cross_dim or dim, inner, bias=bias)
+        self.to_v = nn.Linear(cross_dim or dim, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Dropout(0.0)])
+
+    def forward(self, x, context=None):
+        B, N, _ = x.shape
+        ctx = x if context is None else context
+        q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
+        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.to_out[0](o.transpose(1, 2).reshape(B, N, -1))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+    def forward(self, x):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, head_dim, cross_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, heads, head_dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, heads, head_dim, cross_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, ch, heads, depth, cross_dim, linear_proj):
+        super().__init__()
+        self.linear_proj = linear_proj
+        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.proj_in = nn.Linear(ch, ch) if linear_proj else nn.Conv2d(ch, ch, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, ch // heads, cross_dim) for _ in range(depth)])
+        self.proj_out = nn.Linear(ch, ch) if linear_proj else nn.Conv2d(ch, ch, 1)
+
+    def forward(self, x, context):
+        B, C, H, W = x.shape
+        h = self.norm(x)
+        if self.linear_proj:
+            h = self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C))
+        else:
+            h = self.proj_in(h).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        if self.linear_proj:
+            h = self.proj_out(h).view(B, H, W, C).permute(0, 3, 1, 2)
+        else:
+            h = self.proj_out(h.view(B, H, W, C).permute(0, 3, 1, 2))
+        return h + x
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch, padding=1):
+        super().__init__()
+        self.padding = padding
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        if self.padding == 0:  # VAE encoder: asymmetric pad (diffusers Downsample2D)
+            x = F.pad(x, (0, 1, 0, 1))
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# UNet2DConditionModel
+# ---------------------------------------------------------------------------------------------------
+UNET_CONFIGS = {
+    "sd15": dict(sample_size=64, in_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 attn=(True, True, True, False), transformer_depth=(1, 1, 1, 1), heads=(8, 8, 8, 8),
+                 cross_attention_dim=768, use_linear_projection=False, addition_time_embed_dim=None,
+                 pooled_projection_dim=None),
+    "sd2": dict(sample_size=64, in_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                attn=(True, True, True, False), transformer_depth=(1, 1, 1, 1), heads=(5, 10, 20, 20),
+                cross_attention_dim=1024, use_linear_projection=True, addition_time_embed_dim=None,
+                pooled_projection_dim=None),
+    "sdxl": dict(sample_size=128, in_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+                 attn=(False, True, True), transformer_depth=(1, 2, 10), heads=(5, 10, 20),
+                 cross_attention_dim=2048, use_linear_projection=True, addition_time_embed_dim=256,
+                 pooled_projection_dim=1280),
+}
+
+
+class _DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, layers, attn, heads, depth, cross, linear, downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb) for i in range(layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, depth, cross, linear) for _ in range(layers)]) if attn else None
+        self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if downsample else None
+
+    def forward(self, x, temb, ctx):
+        outs = []
+        for i, r in enumerate(self.resnets):
+            x = r(x, temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+            outs.append(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class _MidBlock(nn.Module):
+    def __init__(self, ch, temb, heads, depth, cross, linear):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb), ResnetBlock2D(ch, ch, temb)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, depth, cross, linear)])
+
+    def forward(self, x, temb, ctx):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, cin, cout, cprev, temb, layers, attn, heads, depth, cross, linear, upsample):
+        super().__init__()
+        rs = []
+        for i in range(layers):
+            skip = cin if i == layers - 1 else cout
+            rs.append(ResnetBlock2D((cprev if i == 0 else cout) + skip, cout, temb))
+        self.resnets = nn.ModuleList(rs)
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, depth, cross, linear) for _ in range(layers)]) if attn else None
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if upsample else None
+
+    def forward(self, x, skips, temb, ctx):
+        for i, r in enumerate(self.resnets):
+            x = r(torch.cat([x, skips.pop()], dim=1), temb)
+            if self.attentions is not None:
+                x = self.attentions[i](x, ctx)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class UNet2DConditionModel(nn.Module):
+    def __init__(self, sample_size, in_channels, block_out_channels, layers_per_block, attn, transformer_depth, heads,
+                 cross_attention_dim, use_linear_projection, addition_time_embed_dim, pooled_projection_dim,
+                 out_channels=4):
+        super().__init__()
+        boc = tuple(block_out_channels)
+        temb = boc[0] * 4
+        self.config = SimpleNamespace(sample_size=sample_size, in_channels=in_channels, block_out_channels=boc,
+                                      cross_attention_dim=cross_attention_dim,
+                                      addition_time_embed_dim=addition_time_embed_dim,
+                                      pooled_projection_dim=pooled_projection_dim)
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        if addition_time_embed_dim:
+            self.add_embedding = TimestepEmbedding(addition_time_embed_dim * 6 + pooled_projection_dim, temb)
+        n = len(boc)
+        self.down_blocks = nn.ModuleList()
+        ch = boc[0]
+        for i in range(n):
+            self.down_blocks.append(_DownBlock(ch, boc[i], temb, layers_per_block, attn[i], heads[i], transformer_depth[i],
+                                               cross_attention_dim, use_linear_projection, downsample=(i < n - 1)))
+            ch = boc[i]
+        self.mid_block = _MidBlock(boc[-1], temb, heads[-1], transformer_depth[-1], cross_attention_dim, use_linear_projection)
+        self.up_blocks = nn.ModuleList()
+        rev, rattn, rheads, rdepth = boc[::-1], attn[::-1], heads[::-1], transformer_depth[::-1]
+        prev = rev[0]
+        for i in range(n):
+            cout, cin = rev[i], rev[min(i + 1, n - 1)]
+            self.up_blocks.append(_UpBlock(cin, cout, prev, temb, layers_per_block + 1, rattn[i], rheads[i], rdepth[i],
+                                           cross_attention_dim, use_linear_projection, upsample=(i < n - 1)))
+            prev = cout
+        self.conv_norm_out = nn.GroupNorm(32, boc[0], eps=1e-5)
+        self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    def embed(self, sample, timestep, added_cond_kwargs):
+        B = sample.shape[0]
+        t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(B)
+        emb = self.time_embedding(timestep_embedding(t, self.config.block_out_channels[0]).to(sample.dtype))
+        if self.config.addition_time_embed_dim:
+            ids = added_cond_kwargs["time_ids"]
+            tid = timestep_embedding(ids.reshape(-1).float(), self.config.addition_time_embed_dim).reshape(B, -1)
+            add = torch.cat([added_cond_kwargs["text_embeds"].to(sample.dtype), tid.to(sample.dtype)], dim=-1)
+            emb = emb + self.add_embedding(add)
+        return emb
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
+        x = sample.to(self.dtype)
+        ctx = encoder_hidden_states.to(self.dtype)
+        emb = self.embed(x, timestep, added_cond_kwargs)
+        x = self.conv_in(x)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, emb, ctx)
+            skips.extend(outs)
+        if down_block_additional_residuals is not None:
+            skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
+        x = self.mid_block(x, emb, ctx)
+        if mid_block_additional_residual is not None:
+            x = x + mid_block_additional_residual
+        for blk in self.up_blocks:
+            x = blk(x, skips, emb, ctx)
+        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        return ModelOutput(sample=x)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ControlNet (diffusers ControlNetModel): the UNet encoder + zero-convs, conditioned on a pixel-space image
+# ---------------------------------------------------------------------------------------------------
+class _CondEmbedding(nn.Module):
+    def __init__(self, out_ch, chans=(16, 32, 96, 256)):
+        super().__init__()
+        self.conv_in = nn.Conv2d(3, chans[0], 3, padding=1)
+        blocks = []
+        for a, b in zip(chans[:-1], chans[1:]):
+            blocks += [nn.Conv2d(a, a, 3, padding=1), nn.Conv2d(a, b, 3, padding=1, stride=2)]
+        self.blocks = nn.ModuleList(blocks)
+        self.conv_out = nn.Conv2d(chans[-1], out_ch, 3, padding=1)
+
+    def forward(self, c):
+        h = F.silu(self.conv_in(c))
+        for b in self.blocks:
+            h = F.silu(b(h))
+        return self.conv_out(h)
+
+
+class ControlNetModel(nn.Module):
+    def __init__(self, unet_cfg):
+        super().__init__()
+        c = dict(unet_cfg)
+        boc = tuple(c["block_out_channels"])
+        temb = boc[0] * 4
+        self.config = SimpleNamespace(**{k: c[k] for k in ("sample_size", "in_channels", "cross_attention_dim",
+                                                           "addition_time_embed_dim", "pooled_projection_dim")},
+                                      block_out_channels=boc)
+        self.conv_in = nn.Conv2d(c["in_channels"], boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        if c["addition_time_embed_dim"]:
+            self.add_embedding = TimestepEmbedding(c["addition_time_embed_dim"] * 6 + c["pooled_projection_dim"], temb)
+        self.controlnet_cond_embedding = _CondEmbedding(boc[0])
+        n = len(boc)
+        self.down_blocks = nn.ModuleList()
+        self.controlnet_down_blocks = nn.ModuleList([nn.Conv2d(boc[0], boc[0], 1)])
+        ch = boc[0]
+        for i in range(n):
+            self.down_blocks.append(_DownBlock(ch, boc[i], temb, c["layers_per_block"], c["attn"][i], c["heads"][i],
+                                               c["transformer_depth"][i], c["cross_attention_dim"],
+                                               c["use_linear_projection"], downsample=(i < n - 1)))
+            ch = boc[i]
+            for _ in range(c["layers_per_block"] + (1 if i < n - 1 else 0)):
+                self.controlnet_down_blocks.append(nn.Conv2d(ch, ch, 1))
+        self.mid_block = _MidBlock(boc[-1], temb, c["heads"][-1], c["transformer_depth"][-1], c["cross_attention_dim"],
+                                   c["use_linear_projection"])
+        self.controlnet_mid_block = nn.Conv2d(boc[-1], boc[-1], 1)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    embed = UNet2DConditionModel.embed
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0,
+                guess_mode=False, return_dict=False, added_cond_kwargs=None, **_):
+        x = sample.to(self.dtype)
+        ctx = encoder_hidden_states.to(self.dtype)
+        emb = self.embed(x, timestep, added_cond_kwargs)
+        x = self.conv_in(x) + self.controlnet_cond_embedding(controlnet_cond.to(self.dtype))
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, emb, ctx)
+            skips.extend(outs)
+        x = self.mid_block(x, emb, ctx)
+        down = [conv(s) * conditioning_scale for conv, s in zip(self.controlnet_down_blocks, skips)]
+        mid = self.controlnet_mid_block(x) * conditioning_scale
+        return down, mid
+
+
+# ---------------------------------------------------------------------------------------------------
+# AutoencoderKL
+# ---------------------------------------------------------------------------------------------------
+class _VaeAttention(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(ch, ch), nn.Linear(ch, ch), nn.Linear(ch, ch)
+        self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Dropout(0.0)])
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        h = self.group_norm(x).view(B, C, H * W).transpose(1, 2)
+        q, k, v = (f(h).unsqueeze(1) for f in (self.to_q, self.to_k, self.to_v))
+        o = F.scaled_dot_product_attention(q, k, v).squeeze(1)
+        return self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W) + x
+
+
+class _VaeMid(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, None, eps=1e-6), ResnetBlock2D(ch, ch, None, eps=1e-6)])
+        self.attentions = nn.ModuleList([_VaeAttention(ch)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class _EncBlock(nn.Module):
+    def __init__(self, cin, cout, layers, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, None, eps=1e-6) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(cout, padding=0)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return self.downsamplers[0](x) if self.downsamplers is not None else x
+
+
+class _DecBlock(nn.Module):
+    def __init__(self, cin, cout, layers, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, None, eps=1e-6) for i in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if up else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return self.upsamplers[0](x) if self.upsamplers is not None else x
+
+
+class _Encoder(nn.Module):
+    def __init__(self, boc, latent_channels, layers=2):
+        super().__init__()
+        self.conv_in = nn.Conv2d(3, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        ch = boc[0]
+        for i, c in enumerate(boc):
+            self.down_blocks.append(_EncBlock(ch, c, layers, down=(i < len(boc) - 1)))
+            ch = c
+        self.mid_block = _VaeMid(ch)
+        self.conv_norm_out = nn.GroupNorm(32, ch, eps=1e-6)
+        self.conv_out = nn.Conv2d(ch, 2 * latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class _Decoder(nn.Module):
+    def __init__(self, boc, latent_channels, layers=2):
+        super().__init__()
+        rev = boc[::-1]
+        self.conv_in = nn.Conv2d(latent_channels, rev[0], 3, padding=1)
+        self.mid_block = _VaeMid(rev[0])
+        self.up_blocks = nn.ModuleList()
+        ch = rev[0]
+        for i, c in enumerate(rev):
+            self.up_blocks.append(_DecBlock(ch, c, layers + 1, up=(i < len(boc) - 1)))
+            ch = c
+        self.conv_norm_out = nn.GroupNorm(32, ch, eps=1e-6)
+        self.conv_out = nn.Conv2d(ch, 3, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class DiagonalGaussian:
+    def __init__(self, moments):
+        self.mean, logvar = moments.chunk(2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=4, scaling_factor=0.18215,
+                 force_upcast=False):
+        super().__init__()
+        self.config = SimpleNamespace(block_out_channels=tuple(block_out_channels), scaling_factor=scaling_factor,
+                                      force_upcast=force_upcast, latent_channels=latent_channels)
+        self.encoder = _Encoder(tuple(block_out_channels), latent_channels)
+        self.decoder = _Decoder(tuple(block_out_channels), latent_channels)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+
+    @property
+    def dtype(self):
+        return self.quant_conv.weight.dtype
+
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    def encode(self, x):
+        return SimpleNamespace(latent_dist=DiagonalGaussian(self.quant_conv(self.encoder(x))))
+
+    def decode(self, z):
+        return SimpleNamespace(sample=self.decoder(self.post_quant_conv(z)))
+
+
+# ---------------------------------------------------------------------------------------------------
+def family(sd_version):
+    if sd_version.startswith("XL"):
+        return "sdxl"
+    if sd_version in ("2.0", "2.1"):
+        return "sd2"
+    if sd_version in ("1.4", "1.5"):
+        return "sd15"
+    raise ValueError(f"no built-in architecture for sd_version={sd_version!r}; pass unet=/vae= explicitly")
+
+
+def _seeded_init(module, seed):
+    """Deterministic synthetic weights (no checkpoints exist offline): PyTorch default init under a private seed,
+    final output convs scaled down so a 50-step loop stays well inside fp32/bf16 range."""
+    dev_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    for m in module.modules():
+        if hasattr(m, "reset_parameters"):
+            m.reset_parameters()
+    torch.random.set_rng_state(dev_state)
+
+
+def load_weights(module, path):
+    """Load an HF-layout ``diffusion_pytorch_model.safetensors`` (same parameter names as diffusers)."""
+    from safetensors.torch import load_file
+    sd = load_file(path)
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    if missing or unexpected:
+        raise RuntimeError(f"{path}: {len(missing)} missing / {len(unexpected)} unexpected keys, e.g. {missing[:3]} {unexpected[:3]}")
+    return module
+
+
+def build_models(sd_version, device="cuda", dtype=None, weights=None, vae_dtype=torch.float32, controlnet=False, seed=0):
+    """(unet, vae[, controlnet]) for the reference's ``sd_version`` keys (ED:128-141).  UNet/ControlNet run in bf16 by
+    default; the VAE stays fp32 like the reference (its decode runs outside autocast, ED:1080-1121, and the encoder is
+    explicitly kept out of autocast, ED:328)."""
+    fam = family(sd_version)
+    cfg = UNET_CONFIGS[fam]
+    dtype = dtype or torch.bfloat16
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(**cfg)
+        vae = AutoencoderKL(scaling_factor=0.13025 if fam == "sdxl" else 0.18215, force_upcast=(fam == "sdxl"))
+        cn = ControlNetModel(cfg) if controlnet else None
+    out = []
+    for k, (m, dt, sub) in enumerate([(unet, dtype, "unet"), (vae, vae_dtype, "vae"), (cn, dtype, "controlnet")]):
+        if m is None:
+            continue
+        m = m.to_empty(device=device)
+        f = os.path.join(weights, sub, "diffusion_pytorch_model.safetensors") if weights else None
+        if f and os.path.isfile(f):
+            load_weights(m, f)
+        else:
+            _seeded_init(m, seed + k)
+        m = m.to(dtype=dt).eval().requires_grad_(False)
+        if dt != torch.float32 or sub != "vae":
+            m = m.to(memory_format=torch.channels_last)
+        out.append(m)
+    return tuple(out)

@@ -13,6 +13,44 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+    Disabled by default: zero overhead on the product path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def start(self):
+        self.events, self.enabled = {}, True
+
+    def stop(self):
+        """-> {kernel: (launches, mean_us, total_ms)}; synchronises."""
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), 1e3 * sum(ms) / len(ms), sum(ms))
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _call(name, *args):
+    fn = getattr(_hip.lib(), name)
+    if TIMER.enabled:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        err = fn(*args)
+        b.record()
+        TIMER.events.setdefault(name, []).append((a, b))
+    else:
+        err = fn(*args)
+    _hip.check(err, name)
+
+
 def _dev(t, dtype=None, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name} must be a tensor on the MI355X (got {type(t).__name__}"
@@ -44,11 +82,10 @@ def gather_views(latent, out, win_y0, win_x0, Sh, Sw, off_y=0, off_x=0, frame=No
     assert off_y >= 0 and off_x >= 0 and off_y + Sh <= PH and off_x + Sw <= PW
     if frame is not None:
         assert tuple(frame.shape) == (C, PH, PW)
-    err = _hip.lib().ed_gather_views(_dev(latent, torch.float32, "latent"), _dev(out, None, "out"), _code(out, "out"),
+    _call("ed_gather_views", _dev(latent, torch.float32, "latent"), _dev(out, None, "out"), _code(out, "out"),
                                      B, C, H, W, _dev(win_y0, torch.int32, "win_y0"), _dev(win_x0, torch.int32, "win_x0"),
                                      V, Sh, Sw, PH, PW, off_y, off_x, _opt(frame, torch.float32, "frame"),
                                      float(divisor), _stream())
-    _hip.check(err, "ed_gather_views")
     return out
 
 
@@ -58,11 +95,10 @@ def scatter_centres(pred, local, n_col_blocks, row_blk, row_src, col_blk, col_sr
     rows, C2, PH, PW = pred.shape
     assert C2 == C and rows % B == 0
     assert row_blk.numel() == H * 2 == row_src.numel() and col_blk.numel() == W * 2 == col_src.numel()
-    err = _hip.lib().ed_scatter_centres(_dev(pred, None, "pred"), _code(pred, "pred"), _dev(local, torch.float32, "local"),
+    _call("ed_scatter_centres", _dev(pred, None, "pred"), _code(pred, "pred"), _dev(local, torch.float32, "local"),
                                         B, C, H, W, PH, PW, n_col_blocks,
                                         _dev(row_blk, torch.int32), _dev(row_src, torch.int32),
                                         _dev(col_blk, torch.int32), _dev(col_src, torch.int32), _stream())
-    _hip.check(err, "ed_scatter_centres")
     return local
 
 
@@ -78,12 +114,11 @@ def pick_assemble(latent, idx, src_row, src_col, out, h, w, off_y=0, off_x=0, fr
         assert tuple(frame.shape) == (C, PH, PW)
     if low is not None:
         assert tuple(low.shape) == (K, B, C, h, w)
-    err = _hip.lib().ed_pick_assemble(_dev(latent, torch.float32, "latent"), _dev(idx, torch.uint8, "idx"),
+    _call("ed_pick_assemble", _dev(latent, torch.float32, "latent"), _dev(idx, torch.uint8, "idx"),
                                       _dev(src_row, torch.int32), _dev(src_col, torch.int32),
                                       _opt(frame, torch.float32, "frame"), _dev(out, None, "out"), _code(out, "out"),
                                       _opt(low, torch.float32, "low"), K, B, C, H, W, h, w, PH, PW, off_y, off_x,
                                       _stream())
-    _hip.check(err, "ed_pick_assemble")
     return out
 
 
@@ -94,10 +129,9 @@ def unpad_direction(unet_out, dirs, uncond_last, off_y=0, off_x=0):
     assert rows == K * 2 * B and C2 == C
     if uncond_last is not None:
         assert tuple(uncond_last.shape) == (B, C, h, w)
-    err = _hip.lib().ed_unpad_direction(_dev(unet_out, None, "unet_out"), _code(unet_out, "unet_out"),
+    _call("ed_unpad_direction", _dev(unet_out, None, "unet_out"), _code(unet_out, "unet_out"),
                                         _dev(dirs, torch.float32, "dirs"), _opt(uncond_last, torch.float32, "uncond_last"),
                                         K, B, C, h, w, PH, PW, off_y, off_x, _stream())
-    _hip.check(err, "ed_unpad_direction")
     return dirs
 
 
@@ -108,13 +142,12 @@ def fill_directions(dirs, idx, inv_row, inv_col, up_row, up_col, down_row, down_
     assert (B2, C2) == (B, C) and tuple(idx.shape) == (K, h * w)
     assert inv_row.numel() == 2 * H and inv_col.numel() == 2 * W and up_row.numel() == H and up_col.numel() == W
     assert down_row.numel() == h and down_col.numel() == w
-    err = _hip.lib().ed_fill_directions(_dev(dirs, torch.float32, "dirs"), _dev(idx, torch.uint8, "idx"),
+    _call("ed_fill_directions", _dev(dirs, torch.float32, "dirs"), _dev(idx, torch.uint8, "idx"),
                                         _dev(inv_row, torch.int32), _dev(inv_col, torch.int32),
                                         _dev(up_row, torch.int32), _dev(up_col, torch.int32),
                                         _dev(down_row, torch.int32), _dev(down_col, torch.int32),
                                         _dev(target, torch.float32, "target"), _opt(low_dir, torch.float32, "low_dir"),
                                         K, B, C, H, W, h, w, _stream())
-    _hip.check(err, "ed_fill_directions")
     return target
 
 
@@ -122,10 +155,9 @@ def cfg_ddim_step(local, direction, x, prev, x0, g, sqrt_beta_t, sqrt_alpha_t, s
     n = x.numel()
     for t in (local, direction, prev, x0):
         assert t.numel() == n
-    err = _hip.lib().ed_cfg_ddim_step(_dev(local, torch.float32), _dev(direction, torch.float32), _dev(x, torch.float32),
+    _call("ed_cfg_ddim_step", _dev(local, torch.float32), _dev(direction, torch.float32), _dev(x, torch.float32),
                                       _dev(prev, torch.float32), _dev(x0, torch.float32), float(g), float(sqrt_beta_t),
                                       float(sqrt_alpha_t), float(sqrt_alpha_prev), float(sqrt_1m_alpha_prev), n, _stream())
-    _hip.check(err, "ed_cfg_ddim_step")
     return prev, x0
 
 
@@ -134,9 +166,8 @@ def undo_step(x_in, noise, coef, x_out):
     n = x_in.numel()
     n_sub = noise.shape[0]
     assert noise.numel() == n_sub * n and coef.numel() == 2 * n_sub and x_out.numel() == n
-    err = _hip.lib().ed_undo_step(_dev(x_in, torch.float32), _dev(noise, torch.float32), _dev(coef, torch.float32),
+    _call("ed_undo_step", _dev(x_in, torch.float32), _dev(noise, torch.float32), _dev(coef, torch.float32),
                                   _dev(x_out, torch.float32), n_sub, n, _stream())
-    _hip.check(err, "ed_undo_step")
     return x_out
 
 
@@ -145,12 +176,11 @@ def rrg_update(prev, x0, low_latent, low_uncond, low_dir, up_row, up_col, out, g
     h, w = low_latent.shape[-2:]
     assert tuple(low_latent.shape) == (B, C, h, w) == tuple(low_uncond.shape) == tuple(low_dir.shape)
     assert up_row.numel() == H and up_col.numel() == W
-    err = _hip.lib().ed_rrg_update(_dev(prev, torch.float32), _dev(x0, torch.float32), _dev(low_latent, torch.float32),
+    _call("ed_rrg_update", _dev(prev, torch.float32), _dev(x0, torch.float32), _dev(low_latent, torch.float32),
                                    _dev(low_uncond, torch.float32), _dev(low_dir, torch.float32),
                                    _dev(up_row, torch.int32), _dev(up_col, torch.int32), _dev(out, torch.float32),
                                    float(g), float(sqrt_beta_t), float(sqrt_alpha_t), float(norm), float(weight),
                                    B, C, H, W, h, w, _stream())
-    _hip.check(err, "ed_rrg_update")
     return out
 
 
@@ -159,10 +189,9 @@ def gather2d(inp, out, src_n, rows, cols):
     _, C, H, W = inp.shape
     N, C2, oh, ow = out.shape
     assert C2 == C and tuple(rows.shape) == (N, oh) and tuple(cols.shape) == (N, ow) and src_n.numel() == N
-    err = _hip.lib().ed_gather2d(_dev(inp, None, "inp"), _code(inp, "inp"), _dev(out, None, "out"), _code(out, "out"),
+    _call("ed_gather2d", _dev(inp, None, "inp"), _code(inp, "inp"), _dev(out, None, "out"), _code(out, "out"),
                                  C, H, W, _dev(src_n, torch.int32), _dev(rows, torch.int32), _dev(cols, torch.int32),
                                  N, oh, ow, _stream())
-    _hip.check(err, "ed_gather2d")
     return out
 
 
@@ -172,10 +201,9 @@ def tile_gather_pad(latent, tiles, tile_y0, tile_x0, scaling_factor):
     T = tile_y0.numel()
     rows, C2, Ts, Ts2 = tiles.shape
     assert rows == T * B and C2 == C and Ts == Ts2
-    err = _hip.lib().ed_tile_gather_pad(_dev(latent, torch.float32), _dev(tiles, None, "tiles"), _code(tiles, "tiles"),
+    _call("ed_tile_gather_pad", _dev(latent, torch.float32), _dev(tiles, None, "tiles"), _code(tiles, "tiles"),
                                         B, C, H, W, _dev(tile_y0, torch.int32), _dev(tile_x0, torch.int32), T, Ts,
                                         float(scaling_factor), _stream())
-    _hip.check(err, "ed_tile_gather_pad")
     return tiles
 
 
@@ -188,9 +216,8 @@ def tile_accumulate_normalise(decoded, image, n_col_tiles, row_tile, row_src, co
     rows, C2, TP, TP2 = decoded.shape
     assert C2 == Cimg and TP == TP2 and rows % B == 0
     assert row_tile.numel() == HP * TILE_MAXC == row_src.numel() and col_tile.numel() == WP * TILE_MAXC == col_src.numel()
-    err = _hip.lib().ed_tile_accumulate_normalise(_dev(decoded, None, "decoded"), _code(decoded, "decoded"),
+    _call("ed_tile_accumulate_normalise", _dev(decoded, None, "decoded"), _code(decoded, "decoded"),
                                                   _dev(image, torch.float32), B, Cimg, HP, WP, TP, n_col_tiles,
                                                   _dev(row_tile, torch.int32), _dev(row_src, torch.int32),
                                                   _dev(col_tile, torch.int32), _dev(col_src, torch.int32), _stream())
-    _hip.check(err, "ed_tile_accumulate_normalise")
     return image
