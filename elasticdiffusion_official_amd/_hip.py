@@ -16,7 +16,7 @@ ROOT_DIR = os.path.dirname(PKG_DIR)
 SRC = os.path.join(PKG_DIR, "csrc", "elastic_kernels.hip")
 INCLUDE = os.path.join(ROOT_DIR, "include")
 SO_PATH = os.path.join(PKG_DIR, "libelastic_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

@@ -15,7 +15,7 @@
 
 #include "elastic_hip.h"
 
-#define ED_ABI_VERSION 1
+#define ED_ABI_VERSION 2
 #define ED_BLOCK 256
 
 namespace {
@@ -185,31 +185,30 @@ k_unpad_direction(const void* __restrict__ uo, float* __restrict__ dirs, float* 
 }
 
 // ---- ed_fill_directions ----------------------------------------------------------------------------
-__device__ __forceinline__ int last_covering_step(const uint8_t* __restrict__ idx, const int32_t* __restrict__ inv_row,
-                                                  const int32_t* __restrict__ inv_col, int K, int h, int w, int Y, int X) {
+// stamp[n*4 + q] = last resampling step whose pick at reduced pixel n was q (int8, -1 = never); built on the host next
+// to the draws.  A full-res pixel is covered by step k iff one of its (<= 2 x 2) pick-grid cells (rr,cc) was picked.
+__device__ __forceinline__ int last_covering_step(const int8_t* __restrict__ stamp, const int32_t* __restrict__ inv_row,
+                                                  const int32_t* __restrict__ inv_col, int K, int w, int Y, int X) {
   int r0 = inv_row[Y * 2], r1 = inv_row[Y * 2 + 1];
   int c0 = inv_col[X * 2], c1 = inv_col[X * 2 + 1];
-  int64_t N = (int64_t)h * w;
-  for (int k = K - 1; k >= 0; --k) {
-    const uint8_t* ik = idx + (int64_t)k * N;
+  int best = -1;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      int rr = a ? r1 : r0;
-      if (rr < 0) continue;
+  for (int a = 0; a < 2; ++a) {
+    int rr = a ? r1 : r0;
+    if (rr < 0) continue;
 #pragma unroll
-      for (int bq = 0; bq < 2; ++bq) {
-        int cc = bq ? c1 : c0;
-        if (cc < 0) continue;
-        int q = ik[(int64_t)(rr >> 1) * w + (cc >> 1)];
-        if (q == ((rr & 1) * 2 + (cc & 1))) return k;
-      }
+    for (int bq = 0; bq < 2; ++bq) {
+      int cc = bq ? c1 : c0;
+      if (cc < 0) continue;
+      int k = stamp[((int64_t)(rr >> 1) * w + (cc >> 1)) * 4 + ((rr & 1) * 2 + (cc & 1))];
+      best = k > best ? k : best;
     }
   }
-  return K - 1;  // fill_all: what no pick reached takes the last step's upsample (ED:643-644)
+  return best < 0 ? K - 1 : best;  // fill_all: what no pick reached takes the last step's upsample (ED:643-644)
 }
 
 __global__ void __launch_bounds__(ED_BLOCK)
-k_fill_directions(const float* __restrict__ dirs, const uint8_t* __restrict__ idx,
+k_fill_directions(const float* __restrict__ dirs, const int8_t* __restrict__ stamp,
                   const int32_t* __restrict__ inv_row, const int32_t* __restrict__ inv_col,
                   const int32_t* __restrict__ up_row, const int32_t* __restrict__ up_col,
                   const int32_t* __restrict__ down_row, const int32_t* __restrict__ down_col,
@@ -237,7 +236,7 @@ k_fill_directions(const float* __restrict__ dirs, const uint8_t* __restrict__ id
     dplane = (int64_t)h * w;
     doff = u;
   }
-  int k = last_covering_step(idx, inv_row, inv_col, K, h, w, Y, X);
+  int k = last_covering_step(stamp, inv_row, inv_col, K, w, Y, X);
   int64_t lplane = (int64_t)h * w;
   int64_t src = (int64_t)up_row[Y] * w + up_col[X];
   int BC = B * C;
@@ -465,12 +464,12 @@ int ed_unpad_direction(const void* unet_out, int dtype, float* dirs, float* unco
   return done();
 }
 
-int ed_fill_directions(const float* dirs, const uint8_t* idx, const int32_t* inv_row, const int32_t* inv_col,
+int ed_fill_directions(const float* dirs, const int8_t* stamp, const int32_t* inv_row, const int32_t* inv_col,
                        const int32_t* up_row, const int32_t* up_col, const int32_t* down_row, const int32_t* down_col,
                        float* target, float* low_dir, int K, int B, int C, int H, int W, int h, int w, void* stream) {
   int64_t n = (int64_t)H * W + (low_dir ? (int64_t)h * w : 0);
   if (n == 0 || K <= 0) return K <= 0 ? (int)hipErrorInvalidValue : 0;
-  ED_LAUNCH(k_fill_directions, n, dirs, idx, inv_row,
+  ED_LAUNCH(k_fill_directions, n, dirs, stamp, inv_row,
                      inv_col, up_row, up_col, down_row, down_col, target, low_dir, K, B, C, H, W, h, w);
   return done();
 }

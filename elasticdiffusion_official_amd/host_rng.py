@@ -70,11 +70,15 @@ class PickSampler:
             idx[bad] = torch.randint(0, hi, (m,))
         return idx
 
-    def draw(self, K, drop_p, after_step, out=None):
+    def draw(self, K, drop_p, after_step, out=None, stamp=None):
         """-> uint8 [K, N].  ``after_step()`` is invoked after each step's draws, where the reference runs the
-        global UNet call whose pad strips re-seed the generators."""
+        global UNet call whose pad strips re-seed the generators.  ``stamp`` (int8 [N,4], optional) receives, per
+        reduced pixel and choice q, the last step that picked q (-1 = never): the K pick masks folded into one table
+        for ed_fill_directions."""
         if out is None:
             out = torch.empty(K, self.N, dtype=torch.uint8)
+        if stamp is not None:
+            stamp.fill_(-1)
         exclude = torch.zeros(self.N, 4, dtype=torch.bool)
         prev = None
         for k in range(K):
@@ -90,6 +94,8 @@ class PickSampler:
             exclude[self.rows, idx] = True
             prev = idx
             out[k].copy_(idx)
+            if stamp is not None:
+                stamp[self.rows, idx] = k
             after_step()
         return out
 

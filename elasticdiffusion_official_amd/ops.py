@@ -135,14 +135,14 @@ def unpad_direction(unet_out, dirs, uncond_last, off_y=0, off_x=0):
     return dirs
 
 
-def fill_directions(dirs, idx, inv_row, inv_col, up_row, up_col, down_row, down_col, target, low_dir=None):
-    """dirs f32 [K,B,C,h,w] + idx u8 [K,h*w] -> target f32 [B,C,H,W] (+ low_dir f32 [B,C,h,w])."""
+def fill_directions(dirs, stamp, inv_row, inv_col, up_row, up_col, down_row, down_col, target, low_dir=None):
+    """dirs f32 [K,B,C,h,w] + stamp i8 [h*w,4] -> target f32 [B,C,H,W] (+ low_dir f32 [B,C,h,w])."""
     K, B, C, h, w = dirs.shape
     B2, C2, H, W = target.shape
-    assert (B2, C2) == (B, C) and tuple(idx.shape) == (K, h * w)
+    assert (B2, C2) == (B, C) and tuple(stamp.shape) == (h * w, 4)
     assert inv_row.numel() == 2 * H and inv_col.numel() == 2 * W and up_row.numel() == H and up_col.numel() == W
     assert down_row.numel() == h and down_col.numel() == w
-    _call("ed_fill_directions", _dev(dirs, torch.float32, "dirs"), _dev(idx, torch.uint8, "idx"),
+    _call("ed_fill_directions", _dev(dirs, torch.float32, "dirs"), _dev(stamp, torch.int8, "stamp"),
                                         _dev(inv_row, torch.int32), _dev(inv_col, torch.int32),
                                         _dev(up_row, torch.int32), _dev(up_col, torch.int32),
                                         _dev(down_row, torch.int32), _dev(down_col, torch.int32),

@@ -39,6 +39,7 @@ class _Stager:
     def __init__(self, depth=4):
         self.depth = depth
         self.rings = {}
+        self.slot_of = {}
 
     def host(self, shape, dtype):
         key = (tuple(shape), dtype)
@@ -46,11 +47,13 @@ class _Stager:
         k = ring["next"] % self.depth
         ring["next"] += 1
         if k >= len(ring["slots"]):
-            ring["slots"].append([torch.empty(shape, dtype=dtype, pin_memory=True), None])
+            buf = torch.empty(shape, dtype=dtype, pin_memory=True)
+            ring["slots"].append([buf, None])
+            self.slot_of[buf.data_ptr()] = ring["slots"][-1]
         slot = ring["slots"][k]
         if slot[1] is not None:
             slot[1].synchronize()  # the async upload that last used this slot must have finished
-        self._last = slot
+            slot[1] = None
         return slot[0]
 
     def upload(self, host_buf, device):
@@ -58,7 +61,7 @@ class _Stager:
         dev.copy_(host_buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._last[1] = ev
+        self.slot_of[host_buf.data_ptr()][1] = ev
         return dev
 
 
@@ -236,7 +239,9 @@ class ElasticDiffusion(nn.Module):
         n_g, n_v = 2 * K * B, P.views.V * B
         # host draws first (they never wait for the GPU)
         idx_host = self._stager.host((K, P.pick.N), torch.uint8)
-        P.sampler.draw(K, drop_p, lambda: host_rng.replay_strip_reseeds(len(P.gpad.strips)), out=idx_host)
+        stamp_host = self._stager.host((P.pick.N, 4), torch.int8)
+        P.sampler.draw(K, drop_p, lambda: host_rng.replay_strip_reseeds(len(P.gpad.strips)), out=idx_host, stamp=stamp_host)
+        stamp = self._stager.upload(stamp_host, dev)
         idx = self._stager.upload(idx_host, dev)
         # view batches as the reference forms them: only their pad-strip reseeds are observable (ED:830, 359)
         if P.vpad.strips:
@@ -268,7 +273,7 @@ class ElasticDiffusion(nn.Module):
         ops.unpad_direction(g_out, dirs, uncond_last, P.gpad.top, P.gpad.left)
         direction = torch.empty_like(x)
         low_dir = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
-        ops.fill_directions(dirs, idx, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction, low_dir)
+        ops.fill_directions(dirs, stamp, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction, low_dir)
         local = torch.empty_like(x)
         ops.scatter_centres(v_out, local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src)
         prev, x0 = torch.empty_like(x), torch.empty_like(x)

@@ -94,14 +94,16 @@ int ed_unpad_direction(const void* unet_out, int dtype, float* dirs, float* unco
  * ed_fill_directions -- ED:633-647 fill_in_from_downsampled_direction applied for K steps in order + ED:688.
  * Per full-resolution pixel: the LAST step whose pick mask covers it supplies the value; if none, step K-1
  * (fill_all).  Value = nearest-upsampled direction of that step at the pixel.
- *   dirs    f32 [K,B,C,h,w];  idx uint8 [K,h*w]
+ *   dirs    f32 [K,B,C,h,w]
+ *   stamp   int8 [h*w, 4]  stamp[n][q] = last step k whose pick at reduced pixel n was q, -1 if never (built on the
+ *                          host from the same draws as idx: the K masks of ED:550-556 folded into one table)
  *   inv_row int32[H*2] / inv_col int32[W*2]  lines of the 2h x 2w pick grid that fold onto latent row/col
  *                                            (ED:446-465 restore_mask_shape, ED:622-628), -1 = none
  *   up_row int32[H] / up_col int32[W]        F.interpolate(nearest) source index reduced<-full (ED:636)
  *   down_row int32[h] / down_col int32[w]    F.interpolate(nearest) source index full<-reduced (ED:688)
  *   target  f32 [B,C,H,W];  low_dir f32 [B,C,h,w] or NULL
  */
-int ed_fill_directions(const float* dirs, const uint8_t* idx,
+int ed_fill_directions(const float* dirs, const int8_t* stamp,
                        const int32_t* inv_row, const int32_t* inv_col,
                        const int32_t* up_row, const int32_t* up_col,
                        const int32_t* down_row, const int32_t* down_col,

@@ -119,7 +119,8 @@ def test_pick_assemble_and_fill_bit_exact(Hl, Wl, h, w, B):
     tail_ref = torch.rand(3)
     # host sampler: same stream
     torch.manual_seed(99)
-    idx = host_rng.PickSampler(h * w).draw(K, 0.7, lambda: None)
+    stamp = torch.empty(h * w, 4, dtype=torch.int8)
+    idx = host_rng.PickSampler(h * w).draw(K, 0.7, lambda: None, stamp=stamp)
     assert torch.equal(torch.rand(3), tail_ref)
     assert torch.equal(idx.long(), torch.stack(idxs))
     # assemble
@@ -149,7 +150,7 @@ def test_pick_assemble_and_fill_bit_exact(Hl, Wl, h, w, B):
     low_dir_ref = F.interpolate(target, size=(h, w), mode="nearest")
     tgt = torch.empty(B, 4, Hl, Wl, device=DEV)
     low_dir = torch.empty(B, 4, h, w, device=DEV)
-    ops.fill_directions(dirs, idx.to(DEV), dev_i32(pp.inv_row), dev_i32(pp.inv_col), dev_i32(pp.up_row),
+    ops.fill_directions(dirs, stamp.to(DEV), dev_i32(pp.inv_row), dev_i32(pp.inv_col), dev_i32(pp.up_row),
                         dev_i32(pp.up_col), dev_i32(pp.down_row), dev_i32(pp.down_col), tgt, low_dir)
     assert torch.equal(tgt.cpu(), target) and torch.equal(low_dir.cpu(), low_dir_ref)
 
