@@ -200,6 +200,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     finite = bool(torch.isfinite(imgs).all())
+    phases = pipe.phase_times()
 
     if rank == 0:
         fam = models.family(wl["sd"])
@@ -251,6 +252,7 @@ def main():
             "images_per_min": round(60 * img_per_s, 3),
             "per_view_unet_ms": round(per_view_ms, 3),
             "finite_output": finite,
+            "phase_ms_last_image": {k: round(v, 1) for k, v in phases.items()},
             "roofline": roof,
             "roofline_e2e": {"bound": "mfma", "achieved": round(e2e_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                              "frac": round(e2e_tf / MFMA_BF16_PEAK_TF, 4),

@@ -13,7 +13,8 @@ import torch  # noqa: F401  (must be imported before the .so so libamdhip64 is a
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT_DIR = os.path.dirname(PKG_DIR)
-SRC = os.path.join(PKG_DIR, "csrc", "elastic_kernels.hip")
+SOURCES = [os.path.join(PKG_DIR, "csrc", "elastic_kernels.hip"), os.path.join(PKG_DIR, "csrc", "unet_kernels.hip")]
+SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT_DIR, "include")
 SO_PATH = os.path.join(PKG_DIR, "libelastic_hip.so")
 ABI_VERSION = 2
@@ -38,6 +39,8 @@ SIGNATURES = {
     "ed_gather2d": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ed_tile_gather_pad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp],
     "ed_tile_accumulate_normalise": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "ed_geglu": [_vp, _vp, _i, _i64, _i, _vp],
+    "ed_groupnorm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
 }
 
 _LIB = None
@@ -45,10 +48,10 @@ _LIB = None
 
 def build_library(force=False, verbose=False):
     """hipcc cross-compiles gfx950 without a GPU; the .so is git-ignored but travels to the GPU box."""
-    if not force and os.path.isfile(SO_PATH) and os.path.getmtime(SO_PATH) >= max(
-            os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, "elastic_hip.h"))):
+    deps = SOURCES + [os.path.join(INCLUDE, "elastic_hip.h")]
+    if not force and os.path.isfile(SO_PATH) and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(d) for d in deps):
         return SO_PATH
-    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE, SRC, "-o", SO_PATH]
+    cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE, *SOURCES, "-o", SO_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

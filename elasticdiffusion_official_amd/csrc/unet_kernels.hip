@@ -1,0 +1,215 @@
+// unet_kernels.hip -- gfx950 fused memory-bound kernels INSIDE the UNet (model side of the hot path's boundary,
+// elastic_diffusion.py:422-426 `self.unet(...)`).  rocprofv3 of the torch-ROCm SDXL UNet at batch 20
+// (profiles/r1_unet_sdxl_b20_kernel_stats.csv) shows ~25 % of the forward in un-fused, partly strided elementwise
+// kernels: GELU + MUL on chunk() views (GEGLU), GroupNorm = moments + affine + separate SiLU, NCHW->token copies.
+// These kernels fuse them: one pass (GEGLU) / two passes (GroupNorm[+SiLU][+token layout]) with 16-byte vector
+// access.  The GEMM / conv / attention contractions stay in hipBLASLt / MIOpen / SDPA (MFMA).
+//
+// Numerics follow the torch kernels they replace (fp32 math, bf16/f16 rounding at the same points), so swapping them
+// in changes UNet outputs by at most a few low-order bits.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "elastic_hip.h"
+
+namespace {
+
+// ---- 16-bit element helpers ------------------------------------------------------------------------
+struct BF16 {
+  static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+};
+struct F16 {
+  static __device__ __forceinline__ float to_f32(uint16_t v) { return __half2float(__ushort_as_half(v)); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return __half_as_ushort(__float2half_rn(f)); }
+};
+
+struct alignas(16) U16x8 { uint16_t v[8]; };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// ---- GEGLU: out[m,i] = in[m,i] * gelu(in[m,I+i]) ---------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_geglu(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int64_t M, int I) {
+  const int vec_per_row = I / 8;
+  const int64_t total = M * vec_per_row;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    int64_t m = t / vec_per_row;
+    int j = (int)(t - m * vec_per_row) * 8;
+    const uint16_t* row = in + m * (2 * (int64_t)I);
+    U16x8 h = *reinterpret_cast<const U16x8*>(row + j);
+    U16x8 g = *reinterpret_cast<const U16x8*>(row + I + j);
+    U16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float ge = T::to_f32(T::from_f32(gelu_erf(T::to_f32(g.v[e]))));  // torch rounds gelu(gate) to 16 bit first
+      o.v[e] = T::from_f32(T::to_f32(h.v[e]) * ge);
+    }
+    *reinterpret_cast<U16x8*>(out + m * (int64_t)I + j) = o;
+  }
+}
+
+// ---- GroupNorm (+SiLU) over NCHW, one workgroup per (sample, group) --------------------------------
+struct Welford {
+  float n, mean, m2;
+};
+__device__ __forceinline__ Welford merge(Welford a, Welford b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  float n = a.n + b.n;
+  float d = b.mean - a.mean;
+  Welford r;
+  r.n = n;
+  r.mean = a.mean + d * (b.n / n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / n);
+  return r;
+}
+
+#define GN_THREADS 512
+
+template <typename T>
+__device__ __forceinline__ void group_stats(const uint16_t* __restrict__ chunk, int64_t len, float eps, float& mean, float& rstd) {
+  // pass 1: per-thread sum / sum of squares over 16-byte vectors (few hundred elements per thread), then Chan merge
+  float s = 0.f, ss = 0.f, cnt = 0.f;
+  for (int64_t i = (int64_t)threadIdx.x * 8; i < len; i += GN_THREADS * 8) {
+    U16x8 v = *reinterpret_cast<const U16x8*>(chunk + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = T::to_f32(v.v[e]);
+      s += f;
+      ss += f * f;
+    }
+    cnt += 8.f;
+  }
+  Welford w;
+  w.n = cnt;
+  w.mean = cnt > 0.f ? s / cnt : 0.f;
+  w.m2 = cnt > 0.f ? fmaxf(ss - s * w.mean, 0.f) : 0.f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Welford o;
+    o.n = __shfl_down(w.n, off, 64);
+    o.mean = __shfl_down(w.mean, off, 64);
+    o.m2 = __shfl_down(w.m2, off, 64);
+    w = merge(w, o);
+  }
+  __shared__ Welford part[GN_THREADS / 64];
+  __shared__ float sh_mean, sh_rstd;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Welford t = part[0];
+    for (int k = 1; k < GN_THREADS / 64; ++k) t = merge(t, part[k]);
+    sh_mean = t.mean;
+    sh_rstd = rsqrtf(t.m2 / t.n + eps);
+  }
+  __syncthreads();
+  mean = sh_mean;
+  rstd = sh_rstd;
+}
+
+// out layout NCHW (TOKENS == false) or [N, HW, C] (TOKENS == true, the transformer's token layout)
+template <typename T, bool ACT, bool TOKENS>
+__global__ void __launch_bounds__(GN_THREADS)
+k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+            uint16_t* __restrict__ out, int C, int HW, int G, float eps) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const int64_t len = (int64_t)cpg * HW;
+  const uint16_t* chunk = x + ((int64_t)n * C + (int64_t)g * cpg) * HW;
+  float mean, rstd;
+  group_stats<T>(chunk, len, eps, mean, rstd);
+  if (!TOKENS) {
+    uint16_t* dst = out + ((int64_t)n * C + (int64_t)g * cpg) * HW;
+    for (int64_t i = (int64_t)threadIdx.x * 8; i < len; i += GN_THREADS * 8) {
+      int c = g * cpg + (int)(i / HW);  // HW % 8 == 0: a vector never straddles channels
+      float a = rstd * T::to_f32(gamma[c]);
+      float b = fmaf(-a, mean, T::to_f32(beta[c]));
+      U16x8 v = *reinterpret_cast<const U16x8*>(chunk + i), o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = T::to_f32(T::from_f32(fmaf(a, T::to_f32(v.v[e]), b)));  // torch rounds the norm output first
+        o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+      }
+      *reinterpret_cast<U16x8*>(dst + i) = o;
+    }
+  } else {
+    // one thread per token p: read its cpg channel values (coalesced across threads for each channel), write cpg
+    // contiguous values of row p
+    for (int p = threadIdx.x; p < HW; p += GN_THREADS) {
+      uint16_t* row = out + ((int64_t)n * HW + p) * C + (int64_t)g * cpg;
+      for (int cc = 0; cc < cpg; cc += 4) {  // cpg % 4 == 0 (checked on the host): 8-byte stores
+        uint16_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int c = g * cpg + cc + e;
+          float a = rstd * T::to_f32(gamma[c]);
+          float b = fmaf(-a, mean, T::to_f32(beta[c]));
+          float y = T::to_f32(T::from_f32(fmaf(a, T::to_f32(chunk[(int64_t)(cc + e) * HW + p]), b)));
+          o4[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+        }
+        uint2 pk;
+        pk.x = (uint32_t)o4[0] | ((uint32_t)o4[1] << 16);
+        pk.y = (uint32_t)o4[2] | ((uint32_t)o4[3] << 16);
+        *reinterpret_cast<uint2*>(row + cc) = pk;
+      }
+    }
+  }
+}
+
+inline int done() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* stream) {
+  if (M == 0 || I == 0) return 0;
+  if (I % 8 != 0 || (((uintptr_t)in | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
+  int64_t total = M * (I / 8);
+  int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == ED_BF16)
+    k_geglu<BF16><<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)in, (uint16_t*)out, M, I);
+  else if (dtype == ED_F16)
+    k_geglu<F16><<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)in, (uint16_t*)out, M, I);
+  else
+    return (int)hipErrorInvalidValue;
+  return done();
+}
+
+int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int N, int C, int HW, int G,
+                 float eps, int act_silu, int tokens_out, void* stream) {
+  if (N == 0) return 0;
+  if (C % G != 0 || HW % 8 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
+  if (tokens_out && (C / G) % 4 != 0) return (int)hipErrorInvalidValue;
+  dim3 grid(N * G), block(GN_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+#define GN_LAUNCH(T, A, K) \
+  k_groupnorm<T, A, K><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)out, C, HW, G, eps)
+#define GN_DISPATCH(T)                         \
+  if (act_silu && !tokens_out) GN_LAUNCH(T, true, false);  \
+  else if (act_silu) GN_LAUNCH(T, true, true);  \
+  else if (!tokens_out) GN_LAUNCH(T, false, false); \
+  else GN_LAUNCH(T, false, true);
+  if (dtype == ED_BF16) {
+    GN_DISPATCH(BF16)
+  } else if (dtype == ED_F16) {
+    GN_DISPATCH(F16)
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+#undef GN_DISPATCH
+#undef GN_LAUNCH
+  return done();
+}
+
+}  // extern "C"

@@ -221,3 +221,22 @@ def tile_accumulate_normalise(decoded, image, n_col_tiles, row_tile, row_src, co
                                                   _dev(row_tile, torch.int32), _dev(row_src, torch.int32),
                                                   _dev(col_tile, torch.int32), _dev(col_src, torch.int32), _stream())
     return image
+
+
+# ---- fused kernels inside the UNet (csrc/unet_kernels.hip) ---------------------------------------------------------
+def geglu(x2, inner):
+    """x2 [..., 2*inner] (16-bit, contiguous) -> [..., inner] = x2[..., :inner] * gelu(x2[..., inner:])."""
+    assert x2.shape[-1] == 2 * inner
+    out = torch.empty(x2.shape[:-1] + (inner,), dtype=x2.dtype, device=x2.device)
+    _call("ed_geglu", _dev(x2, None, "x2"), _dev(out, None, "out"), _code(x2, "x2"), x2.numel() // (2 * inner), inner,
+          _stream())
+    return out
+
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False):
+    """x [N,C,H,W] NCHW 16-bit -> GroupNorm(+SiLU) as [N,C,H,W], or [N,H*W,C] when ``tokens``."""
+    N, C, H, W = x.shape
+    out = torch.empty((N, H * W, C) if tokens else (N, C, H, W), dtype=x.dtype, device=x.device)
+    _call("ed_groupnorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
+          _dev(out, None, "out"), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), int(tokens), _stream())
+    return out

@@ -108,6 +108,20 @@ class ElasticDiffusion(nn.Module):
         self.last_latents = None
         self.stats = {}
 
+    def _mark(self, name):
+        """Phase markers (HIP events on the current stream; read only by ``phase_times`` after a sync)."""
+        if name == "start":
+            self._marks = []
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._marks.append((name, ev))
+
+    def phase_times(self):
+        """-> {phase: ms} of the last generate_image call (synchronises)."""
+        torch.cuda.synchronize()
+        m = self._marks
+        return {b[0]: a[1].elapsed_time(b[1]) for a, b in zip(m[:-1], m[1:])}
+
     # ---- small API surface the reference's callers use (APP:35-39, ED:159-171, 943-950) -----------------
     def set_view_config(self, patch_size=None):
         s = self.unet.config.sample_size
@@ -337,6 +351,7 @@ class ElasticDiffusion(nn.Module):
                          rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
                          progress=_identity_progress, condition_image=None, controlnet_conditioning_scale=1.0,
                          trace=None):
+        self._mark("start")
         P = self._plan(height, width)
         self.default_size = (4 * height, 4 * width)  # ED:969
         n_rrg = num_inference_steps - int(num_inference_steps * rrg_stop_t)
@@ -371,6 +386,7 @@ class ElasticDiffusion(nn.Module):
         self._time_ids = torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32, device=dev)  # ED:232-246, 414-418
         self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
         self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
+        self._mark("setup_done")
         Ks = sorted({R + 1, 1} if repaint else {R + 1})
         emb = {K: self._embed_rows(K, P.views.V, un, co, pun, pco) for K in Ks}
         cond = None
@@ -399,6 +415,7 @@ class ElasticDiffusion(nn.Module):
             if trace is not None:
                 trace.append(x.clone())
         self.last_latents = x
+        self._mark("loop_done")
         return x
 
     # ---- decode (ED:267-310) -----------------------------------------------------------------------
@@ -445,6 +462,7 @@ class ElasticDiffusion(nn.Module):
                                   controlnet_conditioning_scale)
         dec = self.tiled_decode if tiled_decoder else self.decode_latents
         imgs = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])  # decode_bs = 1 (ED:1090, 1121)
+        self._mark("decode_done")
         if grid:
             imgs = torch.cat(list(imgs), dim=-1)[None]  # make_grid(nrows=len) without padding lines
         if output_type == "pt":

@@ -172,6 +172,24 @@ int ed_tile_accumulate_normalise(const void* decoded, int dtype, float* image, i
                                  const int32_t* row_tile, const int32_t* row_src,
                                  const int32_t* col_tile, const int32_t* col_src, void* stream);
 
+/* ---- fused memory-bound kernels inside the UNet (model side of the boundary ED:422-426; csrc/unet_kernels.hip) ---- */
+
+/*
+ * ed_geglu -- the GEGLU activation of the transformer feed-forward (diffusers GEGLU, reached through ED:422):
+ *   out[m,i] = in[m,i] * gelu(in[m,I+i])   (exact erf GELU), 16-bit in/out, fp32 math, torch's rounding points.
+ *   in dtype [M, 2I] row-major, out dtype [M, I]; I % 8 == 0; dtype = ED_F16 | ED_BF16.
+ */
+int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* stream);
+
+/*
+ * ed_groupnorm -- GroupNorm over NCHW 16-bit activations with optional fused SiLU (ResnetBlock2D norm1/norm2,
+ * conv_norm_out) and optional [N,HW,C] token-layout output (Transformer2DModel.norm + the permute that follows).
+ *   x dtype [N,C,HW] (NCHW contiguous), gamma/beta dtype [C], out dtype [N,C,HW] or [N,HW,C];
+ *   HW % 8 == 0, C % G == 0 (and (C/G) % 4 == 0 for tokens_out); dtype = ED_F16 | ED_BF16.
+ */
+int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int N, int C, int HW, int G,
+                 float eps, int act_silu, int tokens_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
