@@ -47,6 +47,44 @@ template <> __device__ __forceinline__ void st<BF16>(void* p, int64_t i, float v
   ((uint16_t*)p)[i] = r;
 }
 
+// 4 consecutive elements: 16-byte (f32) or 8-byte (16-bit) vector access; callers guarantee alignment
+template <typename Tag> __device__ __forceinline__ void st4(void* p, int64_t i, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void st4<F32>(void* p, int64_t i, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>((float*)p + i) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void st4<F16>(void* p, int64_t i, float a, float b, float c, float d) {
+  uint2 pk;
+  pk.x = (uint32_t)__half_as_ushort(__float2half_rn(a)) | ((uint32_t)__half_as_ushort(__float2half_rn(b)) << 16);
+  pk.y = (uint32_t)__half_as_ushort(__float2half_rn(c)) | ((uint32_t)__half_as_ushort(__float2half_rn(d)) << 16);
+  *reinterpret_cast<uint2*>((uint16_t*)p + i) = pk;
+}
+__device__ __forceinline__ uint32_t bf16_bits(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+template <> __device__ __forceinline__ void st4<BF16>(void* p, int64_t i, float a, float b, float c, float d) {
+  uint2 pk;
+  pk.x = bf16_bits(a) | (bf16_bits(b) << 16);
+  pk.y = bf16_bits(c) | (bf16_bits(d) << 16);
+  *reinterpret_cast<uint2*>((uint16_t*)p + i) = pk;
+}
+template <typename Tag> __device__ __forceinline__ float4 ld4(const void* p, int64_t i);
+template <> __device__ __forceinline__ float4 ld4<F32>(const void* p, int64_t i) {
+  return *reinterpret_cast<const float4*>((const float*)p + i);
+}
+template <> __device__ __forceinline__ float4 ld4<F16>(const void* p, int64_t i) {
+  uint2 pk = *reinterpret_cast<const uint2*>((const uint16_t*)p + i);
+  return make_float4(__half2float(__ushort_as_half((uint16_t)(pk.x & 0xffffu))), __half2float(__ushort_as_half((uint16_t)(pk.x >> 16))),
+                     __half2float(__ushort_as_half((uint16_t)(pk.y & 0xffffu))), __half2float(__ushort_as_half((uint16_t)(pk.y >> 16))));
+}
+template <> __device__ __forceinline__ float4 ld4<BF16>(const void* p, int64_t i) {
+  uint2 pk = *reinterpret_cast<const uint2*>((const uint16_t*)p + i);
+  return make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                     __uint_as_float(pk.y & 0xffff0000u));
+}
+
 inline int grid_for(int64_t n, int per_thread = 1) {
   int64_t t = (n + per_thread - 1) / per_thread;
   int64_t g = (t + ED_BLOCK - 1) / ED_BLOCK;
@@ -86,6 +124,45 @@ k_gather_windows(const float* __restrict__ latent, void* __restrict__ out, int B
     val = frame ? frame[((int64_t)c * PH + y) * PW + x] : 0.0f;
   }
   st<Tag>(out, t, val);
+}
+
+// 4 consecutive x per thread; requires PW, Sw, off_x multiples of 4 (a group is entirely inside or outside the window)
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_gather_windows_x4(const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
+                    const int32_t* __restrict__ wy0, const int32_t* __restrict__ wx0, int V, int Sh, int Sw,
+                    int PH, int PW, int off_y, int off_x, const float* __restrict__ frame, float divisor, int use_div) {
+  int PW4 = PW >> 2;
+  int64_t n = (int64_t)V * B * C * PH * PW4;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int x = (int)(t % PW4) << 2;
+  int64_t r = t / PW4;
+  int y = (int)(r % PH);
+  r /= PH;
+  int c = (int)(r % C);
+  r /= C;
+  int b = (int)(r % B);
+  int v = (int)(r / B);
+  int yy = y - off_y, xx = x - off_x;
+  float val[4];
+  if (yy >= 0 && yy < Sh && xx >= 0 && xx < Sw) {
+    int sy = wy0[v] + yy, sx0 = wx0[v] + xx;
+    const float* src = latent + (((int64_t)b * C + c) * H + sy) * W;
+    bool row_ok = sy >= 0 && sy < H;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int sx = sx0 + e;
+      float f = (row_ok && sx >= 0 && sx < W) ? src[sx] : 0.0f;
+      val[e] = (use_div && row_ok && sx >= 0 && sx < W) ? __fdiv_rn(f, divisor) : f;
+    }
+  } else if (frame) {
+    float4 f = *reinterpret_cast<const float4*>(frame + ((int64_t)c * PH + y) * PW + x);
+    val[0] = f.x; val[1] = f.y; val[2] = f.z; val[3] = f.w;
+  } else {
+    val[0] = val[1] = val[2] = val[3] = 0.0f;
+  }
+  st4<Tag>(out, t << 2, val[0], val[1], val[2], val[3]);
 }
 
 // ---- ed_scatter_centres ----------------------------------------------------------------------------
@@ -160,6 +237,55 @@ k_pick_assemble(const float* __restrict__ latent, const uint8_t* __restrict__ id
   st<Tag>(out, row_c * C * plane + e, val);
 }
 
+// 4 consecutive x per thread; requires PW, w, off_x multiples of 4
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_pick_assemble_x4(const float* __restrict__ latent, const uint8_t* __restrict__ idx,
+                   const int32_t* __restrict__ src_row, const int32_t* __restrict__ src_col,
+                   const float* __restrict__ frame, void* __restrict__ out, float* __restrict__ low,
+                   int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x) {
+  int PW4 = PW >> 2;
+  int64_t n = (int64_t)K * B * C * PH * PW4;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int x = (int)(t % PW4) << 2;
+  int64_t r = t / PW4;
+  int y = (int)(r % PH);
+  r /= PH;
+  int c = (int)(r % C);
+  r /= C;
+  int b = (int)(r % B);
+  int k = (int)(r / B);
+  int i = y - off_y, j = x - off_x;
+  float val[4];
+  if (i >= 0 && i < h && j >= 0 && j < w) {
+    uint32_t q4 = *reinterpret_cast<const uint32_t*>(idx + (int64_t)k * h * w + (int64_t)i * w + j);
+    const float* plane = latent + ((int64_t)b * C + c) * H * W;
+    int r0 = src_row[2 * i], r1 = src_row[2 * i + 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int q = (q4 >> (8 * e)) & 0xff;
+      int sy = (q >> 1) ? r1 : r0;
+      int sx = src_col[2 * (j + e) + (q & 1)];
+      val[e] = plane[(int64_t)sy * W + sx];
+    }
+    if (low)
+      *reinterpret_cast<float4*>(low + ((((int64_t)k * B + b) * C + c) * h + i) * w + j) =
+          make_float4(val[0], val[1], val[2], val[3]);
+  } else if (frame) {
+    float4 f = *reinterpret_cast<const float4*>(frame + ((int64_t)c * PH + y) * PW + x);
+    val[0] = f.x; val[1] = f.y; val[2] = f.z; val[3] = f.w;
+  } else {
+    val[0] = val[1] = val[2] = val[3] = 0.0f;
+  }
+  int64_t plane_sz = (int64_t)PH * PW;
+  int64_t e0 = ((int64_t)c * PH + y) * PW + x;
+  int64_t row_u = ((int64_t)k * 2 + 0) * B + b;
+  int64_t row_c = ((int64_t)k * 2 + 1) * B + b;
+  st4<Tag>(out, row_u * C * plane_sz + e0, val[0], val[1], val[2], val[3]);
+  st4<Tag>(out, row_c * C * plane_sz + e0, val[0], val[1], val[2], val[3]);
+}
+
 // ---- ed_unpad_direction ----------------------------------------------------------------------------
 template <typename Tag>
 __global__ void __launch_bounds__(ED_BLOCK)
@@ -182,6 +308,33 @@ k_unpad_direction(const void* __restrict__ uo, float* __restrict__ dirs, float* 
   float cd = ld<Tag>(uo, (((int64_t)k * 2 + 1) * B + b) * C * plane + e);
   dirs[t] = __fsub_rn(cd, u);
   if (uncond_last && k == K - 1) uncond_last[(((int64_t)b * C + c) * h + i) * w + j] = u;
+}
+
+// 4 consecutive j per thread; requires w, PW, off_x multiples of 4
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_unpad_direction_x4(const void* __restrict__ uo, float* __restrict__ dirs, float* __restrict__ uncond_last,
+                     int K, int B, int C, int h, int w, int PH, int PW, int off_y, int off_x) {
+  int w4 = w >> 2;
+  int64_t n = (int64_t)K * B * C * h * w4;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int j = (int)(t % w4) << 2;
+  int64_t r = t / w4;
+  int i = (int)(r % h);
+  r /= h;
+  int c = (int)(r % C);
+  r /= C;
+  int b = (int)(r % B);
+  int k = (int)(r / B);
+  int64_t plane = (int64_t)PH * PW;
+  int64_t e = ((int64_t)c * PH + (i + off_y)) * PW + (j + off_x);
+  float4 u = ld4<Tag>(uo, (((int64_t)k * 2 + 0) * B + b) * C * plane + e);
+  float4 cd = ld4<Tag>(uo, (((int64_t)k * 2 + 1) * B + b) * C * plane + e);
+  float4 d = make_float4(__fsub_rn(cd.x, u.x), __fsub_rn(cd.y, u.y), __fsub_rn(cd.z, u.z), __fsub_rn(cd.w, u.w));
+  *reinterpret_cast<float4*>(dirs + (t << 2)) = d;
+  if (uncond_last && k == K - 1)
+    *reinterpret_cast<float4*>(uncond_last + (((int64_t)b * C + c) * h + i) * w + j) = u;
 }
 
 // ---- ed_fill_directions ----------------------------------------------------------------------------
@@ -343,6 +496,34 @@ k_rrg_update(const float* __restrict__ prev, const float* __restrict__ x0, const
   out[t] = __fadd_rn(prev[t], -grad);
 }
 
+__global__ void __launch_bounds__(ED_BLOCK)
+k_rrg_update_x4(const float* __restrict__ prev, const float* __restrict__ x0, const float* __restrict__ low_latent,
+                const float* __restrict__ low_uncond, const float* __restrict__ low_dir,
+                const int32_t* __restrict__ up_row, const int32_t* __restrict__ up_col, float* __restrict__ out,
+                float g, float sb, float sa, float norm, float weight, int B, int C, int H, int W, int h, int w) {
+  int W4 = W >> 2;
+  int64_t n = (int64_t)B * C * H * W4;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  int X = (int)(t % W4) << 2;
+  int64_t r = t / W4;
+  int Y = (int)(r % H);
+  int64_t bc = r / H;
+  int64_t base = (bc * h + up_row[Y]) * w;
+  float4 p = *reinterpret_cast<const float4*>(prev + (t << 2));
+  float4 z = *reinterpret_cast<const float4*>(x0 + (t << 2));
+  float pv[4] = {p.x, p.y, p.z, p.w}, zv[4] = {z.x, z.y, z.z, z.w}, o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int64_t s = base + up_col[X + e];
+    float eps = __fadd_rn(low_uncond[s], __fmul_rn(g, low_dir[s]));
+    float up = __fdiv_rn(__fsub_rn(low_latent[s], __fmul_rn(sb, eps)), sa);
+    float grad = __fmul_rn(__fmul_rn(norm, __fsub_rn(zv[e], up)), weight);
+    o[e] = __fadd_rn(pv[e], -grad);
+  }
+  *reinterpret_cast<float4*>(out + (t << 2)) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ---- ed_gather2d -----------------------------------------------------------------------------------
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(ED_BLOCK)
@@ -413,6 +594,8 @@ k_tile_accumulate(const void* __restrict__ dec, float* __restrict__ image, int B
   }
 #define ED_LAUNCH(KERNEL, n, ...) KERNEL<<<grid_for(n), ED_BLOCK, 0, (hipStream_t)stream>>>(__VA_ARGS__)
 
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
 extern "C" {
 
 int ed_version(void) { return ED_ABI_VERSION; }
@@ -425,6 +608,12 @@ int ed_gather_views(const float* latent, void* out, int dtype, int B, int C, int
   int64_t n = (int64_t)V * B * C * PH * PW;
   if (n == 0) return 0;
   int use_div = divisor != 1.0f;
+  if ((PW & 3) == 0 && (Sw & 3) == 0 && (off_x & 3) == 0 && aligned16(out) && (!frame || aligned16(frame))) {
+    n >>= 2;
+    ED_LAUNCH_T(dtype, k_gather_windows_x4, n, latent, out, B, C, H, W, win_y0, win_x0, V, Sh, Sw, PH, PW, off_y, off_x,
+                frame, divisor, use_div);
+    return done();
+  }
   ED_LAUNCH_T(dtype, k_gather_windows, n, latent, out, B, C, H, W, win_y0, win_x0, V, Sh, Sw, PH, PW, off_y, off_x,
                                          frame, divisor, use_div);
   return done();
@@ -451,6 +640,13 @@ int ed_pick_assemble(const float* latent, const uint8_t* idx, const int32_t* src
                      int w, int PH, int PW, int off_y, int off_x, void* stream) {
   int64_t n = (int64_t)K * B * C * PH * PW;
   if (n == 0) return 0;
+  if ((PW & 3) == 0 && (w & 3) == 0 && (off_x & 3) == 0 && aligned16(out) && aligned16(idx) &&
+      (!frame || aligned16(frame)) && (!low || aligned16(low))) {
+    n >>= 2;
+    ED_LAUNCH_T(dtype, k_pick_assemble_x4, n, latent, idx, src_row, src_col, frame, out, low, K, B, C, H, W, h, w, PH,
+                PW, off_y, off_x);
+    return done();
+  }
   ED_LAUNCH_T(dtype, k_pick_assemble, n, latent, idx, src_row, src_col, frame, out, low, K, B, C, H, W, h, w, PH, PW,
                                          off_y, off_x);
   return done();
@@ -460,6 +656,12 @@ int ed_unpad_direction(const void* unet_out, int dtype, float* dirs, float* unco
                        int w, int PH, int PW, int off_y, int off_x, void* stream) {
   int64_t n = (int64_t)K * B * C * h * w;
   if (n == 0) return 0;
+  if ((PW & 3) == 0 && (w & 3) == 0 && (off_x & 3) == 0 && aligned16(unet_out) && aligned16(dirs) &&
+      (!uncond_last || aligned16(uncond_last))) {
+    n >>= 2;
+    ED_LAUNCH_T(dtype, k_unpad_direction_x4, n, unet_out, dirs, uncond_last, K, B, C, h, w, PH, PW, off_y, off_x);
+    return done();
+  }
   ED_LAUNCH_T(dtype, k_unpad_direction, n, unet_out, dirs, uncond_last, K, B, C, h, w, PH, PW, off_y, off_x);
   return done();
 }
@@ -473,8 +675,6 @@ int ed_fill_directions(const float* dirs, const int8_t* stamp, const int32_t* in
                      inv_col, up_row, up_col, down_row, down_col, target, low_dir, K, B, C, H, W, h, w);
   return done();
 }
-
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 int ed_cfg_ddim_step(const float* local, const float* direction, const float* x, float* prev, float* x0, float g,
                      float sqrt_beta_t, float sqrt_alpha_t, float sqrt_alpha_prev, float sqrt_one_minus_alpha_prev,
@@ -509,6 +709,12 @@ int ed_rrg_update(const float* prev, const float* x0, const float* low_latent, c
                   int w, void* stream) {
   int64_t n = (int64_t)B * C * H * W;
   if (n == 0) return 0;
+  if ((W & 3) == 0 && aligned16(prev) && aligned16(x0) && aligned16(out)) {
+    n >>= 2;
+    ED_LAUNCH(k_rrg_update_x4, n, prev, x0, low_latent, low_uncond, low_dir, up_row, up_col, out, g, sqrt_beta_t,
+              sqrt_alpha_t, norm, weight, B, C, H, W, h, w);
+    return done();
+  }
   ED_LAUNCH(k_rrg_update, n, prev, x0, low_latent,
                      low_uncond, low_dir, up_row, up_col, out, g, sqrt_beta_t, sqrt_alpha_t, norm, weight, B, C, H, W,
                      h, w);
