@@ -253,6 +253,7 @@ def main():
             "per_view_unet_ms": round(per_view_ms, 3),
             "finite_output": finite,
             "phase_ms_last_image": {k: round(v, 1) for k, v in phases.items()},
+            "host_ms_last_image": {k: round(1e3 * v, 1) for k, v in pipe.host_s.items()},
             "roofline": roof,
             "roofline_e2e": {"bound": "mfma", "achieved": round(e2e_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                              "frac": round(e2e_tf / MFMA_BF16_PEAK_TF, 4),

@@ -47,7 +47,9 @@ def replay_strip_reseeds(n_nonempty_strips):
     re-seeded from it (ED:359).  The md5 seeding and the draws in between are overwritten by this re-seed, so they
     need not be replayed."""
     for _ in range(n_nonempty_strips):
-        torch.manual_seed(int(np.random.randint(100000)))
+        # == torch.manual_seed for the CPU generator (the only one the path draws from); torch.manual_seed would
+        # also re-seed every device generator, ~100x the cost, 100+ times per image
+        torch.default_generator.manual_seed(int(np.random.randint(100000)))
 
 
 class PickSampler:

@@ -18,6 +18,7 @@ fill, which ed_fill_directions reproduces.
 There is no CPU path in this module: without the HIP library and a ROCm device it raises.
 """
 import math
+import time
 
 import numpy as np
 import torch
@@ -252,9 +253,11 @@ class ElasticDiffusion(nn.Module):
         t = self._timesteps[ti]
         n_g, n_v = 2 * K * B, P.views.V * B
         # host draws first (they never wait for the GPU)
+        h0 = time.perf_counter()
         idx_host = self._stager.host((K, P.pick.N), torch.uint8)
         stamp_host = self._stager.host((P.pick.N, 4), torch.int8)
         P.sampler.draw(K, drop_p, lambda: host_rng.replay_strip_reseeds(len(P.gpad.strips)), out=idx_host, stamp=stamp_host)
+        self.host_s["picks"] += time.perf_counter() - h0
         stamp = self._stager.upload(stamp_host, dev)
         idx = self._stager.upload(idx_host, dev)
         # view batches as the reference forms them: only their pad-strip reseeds are observable (ED:830, 359)
@@ -292,6 +295,7 @@ class ElasticDiffusion(nn.Module):
         ops.scatter_centres(v_out, local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src)
         prev, x0 = torch.empty_like(x), torch.empty_like(x)
         ops.cfg_ddim_step(local, direction, x, prev, x0, np.float32(g), *self._step_coef[ti])
+        self.host_s["phase_total"] += time.perf_counter() - h0
         info = {"low_latent": low[K - 1], "uncond_score": uncond_last, "low_direction": low_dir,
                 "direction": direction, "local": local, "init_low": low[0]}
         return prev, x0, info
@@ -299,8 +303,11 @@ class ElasticDiffusion(nn.Module):
     def _undo(self, x, ti_next):
         """ED:692-704; noise drawn on the host generator in the reference's order, staged through pinned memory."""
         n_sub = self._undo_coef.shape[1]
+        h0 = time.perf_counter()
         host = self._stager.host((n_sub,) + tuple(x.shape), torch.float32)
+        self.host_s["stager_wait"] += time.perf_counter() - h0
         host_rng.draw_noise_into(host)
+        self.host_s["noise"] += time.perf_counter() - h0
         noise = self._stager.upload(host, self.device)
         out = torch.empty_like(x)
         ops.undo_step(x, noise, self._undo_coef[ti_next], out)
@@ -352,6 +359,7 @@ class ElasticDiffusion(nn.Module):
                          progress=_identity_progress, condition_image=None, controlnet_conditioning_scale=1.0,
                          trace=None):
         self._mark("start")
+        self.host_s = {"picks": 0.0, "phase_total": 0.0, "noise": 0.0, "stager_wait": 0.0}
         P = self._plan(height, width)
         self.default_size = (4 * height, 4 * width)  # ED:969
         n_rrg = num_inference_steps - int(num_inference_steps * rrg_stop_t)
