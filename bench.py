@@ -82,41 +82,58 @@ def algorithmic_bytes(name, wl_geo):
         "ed_fill_directions": lambda k: k * l + 4 * h * w + L + l,
     }[name]
 
-def kernel_replay(pipe, wl, T, reps=200):
-    """Mean duration of every glue kernel at the workload's launch shapes (phase-A shapes, K = R+1), measured with
-    HIP events on the launch stream around ``reps`` back-to-back launches (per-launch event pairs inside the image
-    loop are floored at ~10 us by event overhead, so they are reported separately as in_situ_us)."""
+def glue_launchers(dev, wl, T, mdt):
+    """Closures launching every glue kernel at the workload's phase-A shapes (K = R+1) on synthetic buffers."""
     import numpy as np
-    from elasticdiffusion_official_amd import ops
-    dev = pipe.device
-    P = pipe._plan(wl["H"], wl["W"])
-    B, C, K, V = 1, 4, wl["R"] + 1, P.views.V
-    mdt = pipe.model_dtype
+    from elasticdiffusion_official_amd import geometry, ops
+    sd = wl["sd"]
+    d = 128 if sd.startswith("XL") else 64
+    Hl, Wl = wl["H"] // 8, wl["W"] // 8
+    h, w = geometry.reduced_size(wl["H"], wl["W"], sd)
+    ws = d // 2
+    pick, views = geometry.PickPlan(Hl, Wl, h, w), geometry.ViewPlan(Hl, Wl, ws, ws, d - ws)
+    gpad, vpad = geometry.PadPlan(h, w, d), geometry.PadPlan(views.Sh, views.Sw, d)
+
+    def i32(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+    B, C, K, V = 1, 4, wl["R"] + 1, views.V
     n_sub = 1000 // T
     f32 = dict(device=dev, dtype=torch.float32)
-    x = torch.randn(B, C, P.Hl, P.Wl, **f32)
-    idx = torch.randint(0, 4, (K, P.pick.N), device=dev, dtype=torch.uint8)
-    stamp = torch.randint(-1, K, (P.pick.N, 4), device=dev, dtype=torch.int8)
-    rows = torch.empty(2 * K * B + V * B, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
-    frame = torch.randn(C, P.gpad.PH, P.gpad.PW, **f32) if P.gpad.padded else None
-    low = torch.empty(K, B, C, P.h, P.w, **f32)
+    x = torch.randn(B, C, Hl, Wl, **f32)
+    idx = torch.randint(0, 4, (K, pick.N), device=dev, dtype=torch.uint8)
+    stamp = torch.randint(-1, K, (pick.N, 4), device=dev, dtype=torch.int8)
+    rows = torch.empty(2 * K * B + V * B, C, gpad.PH, gpad.PW, device=dev, dtype=mdt)
+    frame = torch.randn(C, gpad.PH, gpad.PW, **f32) if gpad.padded else None
+    low = torch.empty(K, B, C, h, w, **f32)
     out = torch.randn(rows.shape, **f32).to(mdt)
-    dirs, unc = torch.empty(K, B, C, P.h, P.w, **f32), torch.empty(B, C, P.h, P.w, **f32)
-    direction, low_dir, local = torch.empty_like(x), torch.empty(B, C, P.h, P.w, **f32), torch.empty_like(x)
-    prev, x0, nxt = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    noise = torch.randn(n_sub, B, C, P.Hl, P.Wl, **f32)
+    dirs, unc = torch.empty(K, B, C, h, w, **f32), torch.empty(B, C, h, w, **f32)
+    direction, low_dir, local = torch.empty_like(x), torch.empty(B, C, h, w, **f32), torch.empty_like(x)
+    prev, x0, nxt = torch.randn_like(x), torch.randn_like(x), torch.empty_like(x)
+    noise = torch.randn(n_sub, B, C, Hl, Wl, **f32)
     coef = torch.rand(n_sub, 2, **f32)
     n_g = 2 * K * B
-    calls = {
-        "ed_pick_assemble": lambda: ops.pick_assemble(x, idx, P.src_row, P.src_col, rows[:n_g], P.h, P.w, P.gpad.top, P.gpad.left, frame, low),
-        "ed_gather_views": lambda: ops.gather_views(x, rows[n_g:], P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, None),
-        "ed_unpad_direction": lambda: ops.unpad_direction(out[:n_g], dirs, unc, P.gpad.top, P.gpad.left),
-        "ed_fill_directions": lambda: ops.fill_directions(dirs, stamp, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction, low_dir),
-        "ed_scatter_centres": lambda: ops.scatter_centres(out[n_g:], local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src),
+    src_row, src_col, inv_row, inv_col = i32(pick.src_row), i32(pick.src_col), i32(pick.inv_row), i32(pick.inv_col)
+    up_row, up_col, down_row, down_col = i32(pick.up_row), i32(pick.up_col), i32(pick.down_row), i32(pick.down_col)
+    win_y0, win_x0 = i32(views.win_y0), i32(views.win_x0)
+    rb, rs, cb, cs = (i32(a) for a in views.cover_tables(vpad.top, vpad.left))
+    return {
+        "ed_pick_assemble": lambda: ops.pick_assemble(x, idx, src_row, src_col, rows[:n_g], h, w, gpad.top, gpad.left, frame, low),
+        "ed_gather_views": lambda: ops.gather_views(x, rows[n_g:], win_y0, win_x0, views.Sh, views.Sw, vpad.top, vpad.left, None),
+        "ed_unpad_direction": lambda: ops.unpad_direction(out[:n_g], dirs, unc, gpad.top, gpad.left),
+        "ed_fill_directions": lambda: ops.fill_directions(dirs, stamp, inv_row, inv_col, up_row, up_col, down_row, down_col, direction, low_dir),
+        "ed_scatter_centres": lambda: ops.scatter_centres(out[n_g:], local, views.n_col_blocks, rb, rs, cb, cs),
         "ed_cfg_ddim_step": lambda: ops.cfg_ddim_step(local, direction, x, prev, x0, 10.0, 0.9, 0.4, 0.5, 0.8),
         "ed_undo_step": lambda: ops.undo_step(prev, noise, coef, nxt),
-        "ed_rrg_update": lambda: ops.rrg_update(prev, x0, low[K - 1], unc, low_dir, P.up_row, P.up_col, nxt, 3.3, 0.9, 0.4, np.float32(2.0 / x.numel()), 800.0),
+        "ed_rrg_update": lambda: ops.rrg_update(prev, x0, low[K - 1], unc, low_dir, up_row, up_col, nxt, 3.3, 0.9, 0.4, np.float32(2.0 / x.numel()), 800.0),
     }
+
+
+def kernel_replay(pipe, wl, T, reps=200):
+    """Mean duration of every glue kernel at the workload's launch shapes (phase-A shapes, K = R+1), measured with
+    HIP events on the launch stream around a hipGraph of ``reps`` back-to-back launches (per-launch event pairs inside
+    the image loop are floored at ~6-10 us by event overhead, so they are reported separately as in_situ_us)."""
+    calls = glue_launchers(pipe.device, wl, T, pipe.model_dtype)
     res = {}
     for name, fn in calls.items():
         for _ in range(5):
@@ -148,6 +165,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--shard-group", type=int, default=0,
+                    help="GPUs that share ONE image by row-sharding (RCCL all-gather per phase); the N/g groups work on "
+                         "different images.  0 = default: 2 when N >= 2 (89 %% modelled efficiency vs 48 %% for g = 8), "
+                         "else 1.  g = N is pure strong scaling of one image.")
+    ap.add_argument("--cache-backgrounds", action="store_true",
+                    help="reuse the noised pad-background frames across images of the same size (off: every image pays)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,22 +180,29 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    g = args.shard_group or (2 if world >= 2 else 1)
+    if world % g:
+        raise SystemExit(f"--shard-group {g} does not divide --gpus {world}")
+    n_groups, group_id, pg = world // g, rank // g, False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        groups = [dist.new_group(ranks=list(range(i * g, (i + 1) * g))) for i in range(n_groups)]  # collective call
+        pg = groups[group_id] if g > 1 else False
 
     from elasticdiffusion_official_amd import ElasticDiffusion, models, ops
 
     wl = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    pipe = ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], model_dtype=dtype)
+    pipe = ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], model_dtype=dtype, process_group=pg,
+                            cache_backgrounds=args.cache_backgrounds)
     kw = dict(height=wl["H"], width=wl["W"], num_inference_steps=args.timesteps, guidance_scale=wl["guidance"],
               resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"], rrg_init_weight=wl["rrg_w"],
               cosine_scale=wl["cosine_scale"], repaint_sampling=True, tiled_decoder=wl["tiled"], output_type="pt")
     prompt, negative = "An astronaut riding a corgi on the moon", "blurry, ugly, poorly drawn, deformed"
 
     def one_image(seed):
-        pipe.seed_everything(seed)
+        pipe.seed_everything(seed * n_groups + group_id)  # same seed within a shard group, different images across groups
         imgs, _ = pipe.generate_image(prompt, negative, **kw)
         return imgs
 
@@ -213,11 +243,11 @@ def main():
         T, R = args.timesteps, wl["R"]
         fs = forward_samples(T, R, V)
         flops_sample = unet_flops_per_sample(fam, dtype)
-        img_per_s = args.steps / elapsed
-        sec_per_img = elapsed / args.steps
-        e2e_tf = fs * flops_sample / sec_per_img / 1e12 / world
+        img_per_s = n_groups * args.steps / elapsed
+        sec_per_img = elapsed / args.steps            # latency of one image inside its shard group
+        e2e_tf = fs * flops_sample / sec_per_img / 1e12 / g
         # per-view UNet ms: whole-image wall time / forward-samples is an upper bound that includes everything else
-        per_view_ms = 1e3 * sec_per_img * world / fs
+        per_view_ms = 1e3 * sec_per_img * g / fs
         geo = dict(B=1, C=4, Hl=Hl, Wl=Wl, h=h, w=w, d=pipe.model_size, K=R + 1, V=V, n_sub=1000 // T, mb=2)
         kern = {}
         replay = kernel_replay(pipe, wl, T) if timing else {}
@@ -244,10 +274,11 @@ def main():
                       else f"images/sec at {T} steps ({args.workload})",
             "value": round(img_per_s, 5), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_img, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if n_groups == 1 else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": args.workload, "height": wl["H"], "width": wl["W"], "denoising_steps": T,
                        "view_batch_size": wl["vbs"], "resampling_steps": R, "views": V, "prompts_per_image": 1,
-                       "unet_forward_samples_per_image": fs, "parallelism": f"row-shard x{world}",
+                       "unet_forward_samples_per_image": fs, "parallelism": f"{n_groups} image group(s) x {g}-way row shard (RCCL all-gather per phase)",
+                       "background_cache": bool(args.cache_backgrounds),
                        "weights": "random-init SDXL architecture (2.567 B params), seed 0", "vae_dtype": "fp32"},
             "images_per_min": round(60 * img_per_s, 3),
             "per_view_unet_ms": round(per_view_ms, 3),

@@ -73,7 +73,7 @@ class ElasticDiffusion(nn.Module):
 
     def __init__(self, device, sd_version="2.0", verbose=False, log_freq=5, view_batch_size=1, low_vram=False, *,
                  unet=None, vae=None, scheduler=None, text_encoder=None, controlnet=None, process_group=None,
-                 model_dtype=None, weights=None):
+                 model_dtype=None, weights=None, cache_backgrounds=False):
         super().__init__()
         device = torch.device(device)
         if device.type != "cuda" or not torch.cuda.is_available():
@@ -103,6 +103,11 @@ class ElasticDiffusion(nn.Module):
         self.model_size = 128 if xl else 64  # d_H, d_W of ED:398-400
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)  # ED:156
         self.sharder = RowSharder(process_group)
+        # The noised-background frames depend only on (pad geometry, timestep schedule, VAE): with cache_backgrounds
+        # they are computed for the first image of a size and reused (the reference's own TODO, ED:340).  Off by
+        # default so that every image pays for its own frames.
+        self.cache_backgrounds = cache_backgrounds
+        self._frame_cache = {}
         self.set_view_config()
         self.default_size = None
         self._stager = _Stager()
@@ -202,6 +207,9 @@ class ElasticDiffusion(nn.Module):
         T = len(timesteps)
         if not pad.padded:
             return None
+        key = (pad.h, pad.w, pad.d, C, tuple(int(t) for t in timesteps))
+        if self.cache_backgrounds and key in self._frame_cache:
+            return self._frame_cache[key]
         frames = torch.zeros(T, C, pad.PH, pad.PW, device=self.device, dtype=torch.float32)
         sf = self.vae.config.scaling_factor
         s = self.vae_scale_factor
@@ -221,6 +229,8 @@ class ElasticDiffusion(nn.Module):
                 enc = (dist.mean.float() + dist.std.float() * post[a:b]) * sf
                 noised = coef[a:b, 0].view(-1, 1, 1, 1) * enc + coef[a:b, 1].view(-1, 1, 1, 1) * fwd[a:b]
                 frames[a:b, :, y0:y0 + Hs, x0:x0 + Ws] = noised
+        if self.cache_backgrounds:
+            self._frame_cache[key] = frames
         return frames
 
     def _embed_rows(self, K, V, un, co, pun, pco):

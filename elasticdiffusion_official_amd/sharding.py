@@ -31,7 +31,9 @@ def row_partition(n_rows, world_size):
 class RowSharder:
     def __init__(self, process_group=None):
         self.group = process_group
-        if dist.is_available() and dist.is_initialized():
+        if process_group is False:  # explicit "do not shard" even though torch.distributed is initialised (replicas)
+            self.group, self.world_size, self.rank = None, 1, 0
+        elif dist.is_available() and dist.is_initialized():
             self.world_size = dist.get_world_size(process_group)
             self.rank = dist.get_rank(process_group)
         else:
@@ -57,7 +59,12 @@ class RowSharder:
 
         local = fn(take(x_rows), take(text), take(pooled), take(cond)).contiguous()
         full = torch.empty((per * self.world_size,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(full, local, group=self.group)
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test-only transport (two ranks sharing one GPU cannot use RCCL): gloo stages device tensors via the host
+            parts = list(full.view((self.world_size, per) + tuple(local.shape[1:])).unbind(0))
+            dist.all_gather(parts, local, group=self.group)
+        else:
+            dist.all_gather_into_tensor(full, local, group=self.group)
         if per * self.world_size == n:
             return full
         return full.index_select(0, keep).contiguous()

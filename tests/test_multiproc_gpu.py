@@ -1,0 +1,71 @@
+"""-m gpu: the row-sharded multi-rank path end to end.  Two (three) processes share the single GPU of the test box and
+talk over gloo (RCCL refuses two ranks on one device); every rank must produce the SAME latent as the reference's
+golden vector -- i.e. sharding + all-gather is bit-transparent -- and end with the reference's host RNG state."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, ret):
+    import torch.distributed as dist
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    from tests.fakes import FakeControlNet, FakeUNet, FakeVAE
+    from tests.golden import cases
+    from tests.test_hip_parity import _embed_fn
+    from oracle import elastic_oracle as eo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = cases.E2E_CASES[name]
+        xl = c["sd"].startswith("XL")
+        cn = c.get("controlnet", False)
+        kw = dict(cases.E2E_KW)
+        kw.update(c.get("kw", {}))
+        if cn:
+            ds = eo.get_downsample_size(c["H"], c["W"], c["sd"])
+            kw.update(condition_image=cases.synthetic_condition(ds[0] * 8, ds[1] * 8), controlnet_conditioning_scale=0.2)
+        pipe = ElasticDiffusion("cuda:0", c["sd"], view_batch_size=c["vbs"], unet=FakeUNet(c["sample"], xl=xl),
+                                vae=FakeVAE(), text_encoder=_embed_fn(xl), controlnet=FakeControlNet() if cn else None)
+        assert pipe.sharder.world_size == world
+        pipe.seed_everything(c["seed"])
+        imgs, _ = pipe.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                                      resampling_steps=c["R"], tiled_decoder=bool(c.get("tiled")), output_type="pt", **kw)
+        tail = torch.rand(4).numpy()
+        ret[rank] = (pipe.last_latents.cpu().numpy(), imgs.cpu().numpy(), tail)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "cfg2_sd_512x1024"), (3, "cfg3_xl_1024x2048"), (2, "tiled_sd_640x512"),
+                                        (2, "cn_sd_512x1024")])
+def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
+    g = np.load(os.path.join(golden_dir, "g8_end_to_end.npz"))
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    want = g[f"{name}/latent"]
+    for r in range(world):
+        z, img, tail = ret[r]
+        rel = np.linalg.norm(z - want) / np.linalg.norm(want)
+        assert rel < 1e-4, (r, rel)
+        np.testing.assert_array_equal(tail, g[f"{name}/rng_tail"])
+        np.testing.assert_array_equal(z, ret[0][0])      # all ranks bit-identical
+        np.testing.assert_array_equal(img, ret[0][1])

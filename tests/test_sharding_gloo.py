@@ -88,3 +88,34 @@ def test_single_process_is_identity():
     sh = RowSharder()
     x = torch.randn(5, 4, 8, 8)
     assert torch.equal(sh.run(_model, x, None, None, None), _model(x, None, None, None))
+
+
+def _group_worker(rank, world, port, g, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        groups = [dist.new_group(ranks=list(range(i * g, (i + 1) * g))) for i in range(world // g)]
+        sh = RowSharder(groups[rank // g])
+        ok = (sh.world_size, sh.rank) == (g, rank % g)
+        x = torch.randn(7, 4, 8, 8, generator=torch.Generator().manual_seed(100 + rank // g))  # per-group data
+        ok = ok and torch.equal(sh.run(_model, x, None, None, None), _model(x, None, None, None))
+        solo = RowSharder(False)
+        ok = ok and (solo.world_size, solo.rank) == (1, 0) and torch.equal(solo.run(_model, x), _model(x, None, None, None))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sub_groups_shard_independently():
+    """bench.py's N-GPU layout: N/g groups of g ranks, each group row-shards its own image."""
+    world, g = 4, 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, g, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) is True for r in range(world)), dict(ret)

@@ -50,9 +50,13 @@ def test_groupnorm(dtype, N, C, H, W, silu, tokens):
         want = want.permute(0, 2, 3, 1).reshape(N, H * W, C)
     got = ops.groupnorm(x, w, b, 32, 1e-5, silu=silu, tokens=tokens)
     assert got.shape == want.shape
-    # group statistics differ in summation order from torch's Welford: allow 1e-2 absolute on O(1) normalised values
-    assert (got.float() - want.float()).abs().max().item() < 3e-2
-    assert (got == want).float().mean().item() > 0.9
+    # group statistics differ in summation order from torch's Welford, which can flip the last bit of an output:
+    # every element within 2 ulp of the 16-bit type (relative 2^-7 for bf16, 2^-10 for f16), mean error far below 1 ulp
+    g, w_ = got.float(), want.float()
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    assert bool(((g - w_).abs() <= 2 * ulp * w_.abs() + 1e-3).all()), float((g - w_).abs().max())
+    assert float((g - w_).abs().mean() / w_.abs().mean()) < ulp / 4
+    assert (got == want).float().mean().item() > 0.7
 
 
 def test_unet_fused_vs_unfused_close():
