@@ -1,0 +1,91 @@
+"""hipGraph capture of the model forward (torch.cuda.CUDAGraph is a hipGraph on ROCm).
+
+One UNet forward is ~1900 kernel launches; measured on the MI355X box the Python/eager launch path costs ~85 ms of
+host time per forward, which made the loop HOST-bound (profiles/r1_bench_trace_summary.txt: the GPU idled ~20 ms per
+timestep on 1 GPU and would idle far more once rows are sharded over ranks).  Capturing the forward per batch shape
+and replaying it makes the host cost of a phase a handful of launches, so the host RNG work runs far ahead of the GPU.
+
+Static buffers: a hipGraph replays fixed addresses, so each captured shape owns its input tensors (model rows, 0-d
+timestep, text / pooled / condition rows) and its output tensor.  The assemble kernels write the model rows straight
+into the static input (``input_rows``), so no extra copy is added to the hot loop; side inputs are copied once per image.
+"""
+import warnings
+
+import torch
+
+
+class GraphedForward:
+    def __init__(self, fwd, enabled=True, warmup_iters=2):
+        self.fwd = fwd
+        self.enabled = enabled and torch.cuda.is_available()
+        self.warmup_iters = warmup_iters
+        self.entries = {}
+        self.epoch = 0
+
+    def new_image(self):
+        """Side inputs (text / pooled / condition rows) may have changed: re-copy them on next use."""
+        self.epoch += 1
+
+    @staticmethod
+    def _key(shape, dtype, cond):
+        return (tuple(shape), dtype, None if cond is None else (tuple(cond.shape), cond.dtype))
+
+    def input_rows(self, shape, dtype, device, cond=None):
+        """The static model-input tensor for this batch shape (allocated on first request)."""
+        if not self.enabled:
+            return torch.empty(shape, dtype=dtype, device=device)
+        key = self._key(shape, dtype, cond)
+        ent = self.entries.get(key)
+        if ent is None:
+            ent = {"x": torch.empty(shape, dtype=dtype, device=device), "graph": None, "epoch": -1, "eager": False}
+            self.entries[key] = ent
+        return ent["x"]
+
+    def _capture(self, ent, t, text, pooled, cond):
+        x = ent["x"]
+        ent["t"] = t.clone()
+        ent["text"] = None if text is None else text.clone()
+        ent["pooled"] = None if pooled is None else pooled.clone()
+        ent["cond"] = None if cond is None else cond.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up off the capture: MIOpen find / allocator growth happen here
+            for _ in range(self.warmup_iters):
+                self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ent["out"] = self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
+        ent["graph"] = graph
+
+    def __call__(self, x, t, text=None, pooled=None, cond=None):
+        if not self.enabled:
+            return self.fwd(x, t, text, pooled, cond)
+        key = self._key(x.shape, x.dtype, cond)
+        ent = self.entries.get(key)
+        if ent is None:
+            ent = {"x": torch.empty_like(x), "graph": None, "epoch": -1, "eager": False}
+            self.entries[key] = ent
+        if ent["eager"]:
+            return self.fwd(x, t, text, pooled, cond)
+        if x.data_ptr() != ent["x"].data_ptr():
+            ent["x"].copy_(x)
+        if ent["graph"] is None:
+            try:
+                self._capture(ent, t, text, pooled, cond)
+            except Exception as e:  # noqa: BLE001 -- a library that cannot be captured must not take the path down
+                warnings.warn(f"hipGraph capture failed for rows {tuple(x.shape)} ({type(e).__name__}: {e}); "
+                              "running this shape eagerly")
+                ent["eager"] = True
+                torch.cuda.synchronize()
+                return self.fwd(x, t, text, pooled, cond)
+            ent["epoch"] = self.epoch
+        ent["t"].copy_(t)
+        if ent["epoch"] != self.epoch:
+            for name, src in (("text", text), ("pooled", pooled), ("cond", cond)):
+                if src is not None:
+                    ent[name].copy_(src)
+            ent["epoch"] = self.epoch
+        ent["graph"].replay()
+        return ent["out"]

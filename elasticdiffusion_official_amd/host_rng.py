@@ -58,18 +58,24 @@ class PickSampler:
     def __init__(self, N):
         self.N = N
         self.rows = torch.arange(N)
+        self.base = self.rows * 4
 
     def _sample_excluding(self, exclude, hi=4, max_iteration=50):
+        """ED:501-520.  Every draw is a ``torch.randint`` on the global CPU generator with the reference's sizes, in
+        the reference's order.  The mask bookkeeping uses flat 1-D gathers / masked_scatter_: torch's 2-D advanced
+        indexing ``mask[arange(N), idx]`` costs milliseconds per call once torch has many intra-op threads (it did on
+        the 256-core GPU box), and this loop runs ~40 rounds per resampling step."""
+        flat = exclude.view(-1)
         idx = torch.randint(0, hi, (self.N,))
-        bad = exclude[self.rows, idx]
-        m = int(bad.sum())
+        bad = flat.index_select(0, self.base + idx)
+        m = int(torch.count_nonzero(bad))
         while m > 0 and max_iteration > 0:
-            idx[bad] = torch.randint(0, hi, (m,))
-            bad = exclude[self.rows, idx]
-            m = int(bad.sum())
+            idx.masked_scatter_(bad, torch.randint(0, hi, (m,)))  # == idx[bad] = randint(...): filled in index order
+            bad = flat.index_select(0, self.base + idx)
+            m = int(torch.count_nonzero(bad))
             max_iteration -= 1
         if m > 0:  # every choice excluded for some pixels: unconstrained redraw (ED:514-518)
-            idx[bad] = torch.randint(0, hi, (m,))
+            idx.masked_scatter_(bad, torch.randint(0, hi, (m,)))
         return idx
 
     def draw(self, K, drop_p, after_step, out=None, stamp=None):
@@ -93,11 +99,12 @@ class PickSampler:
                 drop[drop <= 100 * drop_p] = 0
                 drop[drop >= 100 * drop_p] = 1
                 idx = idx * drop + prev * (1 - drop)
-            exclude[self.rows, idx] = True
+            flat_pos = self.base + idx
+            exclude.view(-1).index_fill_(0, flat_pos, True)
             prev = idx
             out[k].copy_(idx)
             if stamp is not None:
-                stamp[self.rows, idx] = k
+                stamp.view(-1).index_fill_(0, flat_pos, k)
             after_step()
         return out
 

@@ -40,7 +40,7 @@ TIMER = KernelTimer()
 
 def _call(name, *args):
     fn = getattr(_hip.lib(), name)
-    if TIMER.enabled:
+    if TIMER.enabled and not torch.cuda.is_current_stream_capturing():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         err = fn(*args)

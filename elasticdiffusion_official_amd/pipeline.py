@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import geometry, host_rng, ops
+from .graphs import GraphedForward
 from .schedule import CosineScheduler, DDIMSchedule
 from .sharding import RowSharder
 
@@ -41,6 +42,7 @@ class _Stager:
         self.depth = depth
         self.rings = {}
         self.slot_of = {}
+        self.waited = 0.0  # seconds the host spent blocked because it was a full ring ahead of the GPU
 
     def host(self, shape, dtype):
         key = (tuple(shape), dtype)
@@ -53,7 +55,9 @@ class _Stager:
             self.slot_of[buf.data_ptr()] = ring["slots"][-1]
         slot = ring["slots"][k]
         if slot[1] is not None:
+            w0 = time.perf_counter()
             slot[1].synchronize()  # the async upload that last used this slot must have finished
+            self.waited += time.perf_counter() - w0
             slot[1] = None
         return slot[0]
 
@@ -73,7 +77,7 @@ class ElasticDiffusion(nn.Module):
 
     def __init__(self, device, sd_version="2.0", verbose=False, log_freq=5, view_batch_size=1, low_vram=False, *,
                  unet=None, vae=None, scheduler=None, text_encoder=None, controlnet=None, process_group=None,
-                 model_dtype=None, weights=None, cache_backgrounds=False):
+                 model_dtype=None, weights=None, cache_backgrounds=False, use_graphs=True):
         super().__init__()
         device = torch.device(device)
         if device.type != "cuda" or not torch.cuda.is_available():
@@ -108,6 +112,9 @@ class ElasticDiffusion(nn.Module):
         # default so that every image pays for its own frames.
         self.cache_backgrounds = cache_backgrounds
         self._frame_cache = {}
+        # one hipGraph per model batch shape (graphs.py); falls back to eager launches if a capture fails
+        self._runner = GraphedForward(self._forward_rows, enabled=use_graphs)
+        self._time_ids = torch.zeros(1, 6, dtype=torch.float32, device=device)  # persistent: captured by the graphs
         self.set_view_config()
         self.default_size = None
         self._stager = _Stager()
@@ -241,20 +248,22 @@ class ElasticDiffusion(nn.Module):
         return text, pooled
 
     # ---- model boundary ----------------------------------------------------------------------------
-    def _run_model(self, x_rows, t_dev, text, pooled, cond_rows=None, cn_scale=1.0):
-        """ED:413-426 / EDC:476-518 for an arbitrary batch of d x d rows; rows are sharded across ranks."""
-        def fwd(x, txt, pl, cond):
-            kw = {}
-            if self.sd_version.startswith("XL"):
-                ids = self._time_ids.to(txt.dtype).expand(x.shape[0], -1)
-                kw["added_cond_kwargs"] = {"text_embeds": pl, "time_ids": ids}
-            if cond is not None:
-                down, mid = self.controlnet(x, t_dev, encoder_hidden_states=txt, controlnet_cond=cond,
-                                            conditioning_scale=cn_scale, guess_mode=False, return_dict=False, **kw)
-                kw["down_block_additional_residuals"], kw["mid_block_additional_residual"] = down, mid
-            return self.unet(x, t_dev, encoder_hidden_states=txt, **kw)["sample"].contiguous()
+    def _forward_rows(self, x, t_dev, txt, pl, cond):
+        """ED:413-426 / EDC:476-518 for an arbitrary batch of d x d rows (this is what a hipGraph captures)."""
+        kw = {}
+        if self.sd_version.startswith("XL"):
+            ids = self._time_ids.to(txt.dtype).expand(x.shape[0], -1)
+            kw["added_cond_kwargs"] = {"text_embeds": pl, "time_ids": ids}
+        if cond is not None:
+            down, mid = self.controlnet(x, t_dev, encoder_hidden_states=txt, controlnet_cond=cond,
+                                        conditioning_scale=self._cn_scale, guess_mode=False, return_dict=False, **kw)
+            kw["down_block_additional_residuals"], kw["mid_block_additional_residual"] = down, mid
+        return self.unet(x, t_dev, encoder_hidden_states=txt, **kw)["sample"].contiguous()
 
-        return self.sharder.run(fwd, x_rows, text, pooled, cond_rows)
+    def _run_model(self, x_rows, t_dev, text, pooled, cond_rows=None):
+        """Rows are sharded across ranks (sharding.py); each rank's share runs as one (graph-replayed) forward."""
+        return self.sharder.run(lambda x, txt, pl, cond: self._runner(x, t_dev, txt, pl, cond),
+                                x_rows, text, pooled, cond_rows)
 
     # ---- one estimation phase (ED:1016-1035 or ED:1043-1056) ---------------------------------------
     def _phase(self, P, x, ti, K, g, drop_p, emb, cond=None):
@@ -278,7 +287,11 @@ class ElasticDiffusion(nn.Module):
         vframe = None if self._vframes is None else self._vframes[ti]
         low = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
         if P.one_batch:
-            rows = torch.empty(n_g + n_v, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
+            shape = (n_g + n_v, C, P.gpad.PH, P.gpad.PW)
+            # single rank: assemble straight into the graph's static input; sharded: into a scratch batch that
+            # the sharder slices per rank
+            rows = (self._runner.input_rows(shape, mdt, dev, None if cond is None else cond[K])
+                    if self.sharder.world_size == 1 else torch.empty(shape, device=dev, dtype=mdt))
             g_rows, v_rows = rows[:n_g], rows[n_g:]
         else:
             g_rows = torch.empty(n_g, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
@@ -288,13 +301,14 @@ class ElasticDiffusion(nn.Module):
         text, pooled = emb[K]
         t_dev = self._t_dev[ti]
         if P.one_batch:
-            out = self._run_model(rows, t_dev, text, pooled, None if cond is None else cond[K], self._cn_scale)
+            out = self._run_model(rows, t_dev, text, pooled, None if cond is None else cond[K])
             g_out, v_out = out[:n_g], out[n_g:]
         else:
-            g_out = self._run_model(g_rows, t_dev, text[:n_g], pooled[:n_g],
-                                    None if cond is None else cond[K][0], self._cn_scale)
-            v_out = self._run_model(v_rows, t_dev, text[n_g:], pooled[n_g:],
-                                    None if cond is None else cond[K][1], self._cn_scale)
+            g_out = self._run_model(g_rows, t_dev, text[:n_g].contiguous(), pooled[:n_g].contiguous(),
+                                    None if cond is None else cond[K][0])
+            v_out = self._run_model(v_rows, t_dev, text[n_g:].contiguous(), pooled[n_g:].contiguous(),
+                                    None if cond is None else cond[K][1])
+            g_out, v_out = g_out.clone(), v_out  # two calls may share one graph output buffer when shapes coincide
         dirs = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
         uncond_last = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
         ops.unpad_direction(g_out, dirs, uncond_last, P.gpad.top, P.gpad.left)
@@ -370,6 +384,7 @@ class ElasticDiffusion(nn.Module):
                          trace=None):
         self._mark("start")
         self.host_s = {"picks": 0.0, "phase_total": 0.0, "noise": 0.0, "stager_wait": 0.0}
+        self._stager.waited = 0.0
         P = self._plan(height, width)
         self.default_size = (4 * height, 4 * width)  # ED:969
         n_rrg = num_inference_steps - int(num_inference_steps * rrg_stop_t)
@@ -401,13 +416,16 @@ class ElasticDiffusion(nn.Module):
             rows = [self.scheduler.undo_coefficients(t) for t in ts[1:]]
             self._undo_coef = torch.stack(rows[:1] + rows).to(dev) if rows else None
         d0, d1 = self.default_size
-        self._time_ids = torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32, device=dev)  # ED:232-246, 414-418
+        self._time_ids.copy_(torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32))  # ED:232-246, 414-418
+        self._runner.new_image()
         self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
         self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
         self._mark("setup_done")
         Ks = sorted({R + 1, 1} if repaint else {R + 1})
         emb = {K: self._embed_rows(K, P.views.V, un, co, pun, pco) for K in Ks}
         cond = None
+        if getattr(self, "_cn_scale", controlnet_conditioning_scale) != controlnet_conditioning_scale:
+            self._runner.entries.clear()  # the scale is a constant inside captured graphs
         self._cn_scale = controlnet_conditioning_scale
         if condition_image is not None:
             if self.controlnet is None:
@@ -433,6 +451,7 @@ class ElasticDiffusion(nn.Module):
             if trace is not None:
                 trace.append(x.clone())
         self.last_latents = x
+        self.host_s["blocked_ahead_of_gpu"] = self._stager.waited
         self._mark("loop_done")
         return x
 

@@ -191,3 +191,30 @@ def test_tile_plan_matches_reference_tiling():
             count[h0 * 8:h1 * 8, w0 * 8:w1 * 8] += 1
         got = (rt.reshape(-1, 4) >= 0).sum(1)[:, None] * (ct.reshape(-1, 4) >= 0).sum(1)[None, :]
         np.testing.assert_array_equal(got, count)
+
+
+@pytest.mark.parametrize("h,w,K,seed", [(32, 64, 4, 0), (64, 128, 8, 1), (8, 8, 12, 2)])
+def test_pick_sampler_draws_equal_oracle_chain(h, w, K, seed):
+    """Same picks as the oracle's random_downsample chain (incl. exhausted-choice fallback at K > 4), same generator
+    end state, and a stamp table that reproduces 'last step that picked q'."""
+    orc = eo.ElasticOracle(FakeUNet(64), FakeVAE(), DDIMOracle())
+    N = h * w
+    x = torch.zeros(1, 1, 2 * h, 2 * w)
+    torch.manual_seed(seed)
+    prev, exclude, want = None, None, []
+    for k in range(K):
+        _, _, prev = orc.random_downsample(x, exclude, prev, drop_p=0.7, nearest=(k == 0))
+        if exclude is None:
+            exclude = torch.zeros(N, 4, dtype=torch.bool)
+        exclude[torch.arange(N), prev] = True
+        want.append(prev.clone())
+    tail = torch.rand(3)
+    torch.manual_seed(seed)
+    stamp = torch.empty(N, 4, dtype=torch.int8)
+    got = host_rng.PickSampler(N).draw(K, 0.7, lambda: None, stamp=stamp)
+    assert torch.equal(torch.rand(3), tail)
+    assert torch.equal(got.long(), torch.stack(want))
+    ref = torch.full((N, 4), -1, dtype=torch.int8)
+    for k in range(K):
+        ref[torch.arange(N), want[k]] = k
+    assert torch.equal(stamp, ref)
