@@ -69,6 +69,11 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
+# 1x1 shortcut convolutions as one strided-batched GEMM with the residual folded in (beta = 1): replaces MIOpen's
+# im2col + GEMM + bias kernels and the separate residual add.  Toggle for A/B measurements.
+SHORTCUT_AS_GEMM = True
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, cin, cout, temb_dim=None, eps=1e-5, groups=32):
         super().__init__()
@@ -83,8 +88,18 @@ class ResnetBlock2D(nn.Module):
         h = self.conv1(group_norm_act(self.norm1, x, silu=True))
         if self.time_emb_proj is not None:
             h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(group_norm_act(self.norm2, h, silu=True))
-        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+        a = group_norm_act(self.norm2, h, silu=True)
+        sc = self.conv_shortcut
+        if sc is not None and SHORTCUT_AS_GEMM and _fusable(x):
+            # out = W_sc x + (conv2(a) + b_conv2 + b_sc): the shortcut bias rides on conv2's bias, the residual sum is
+            # the GEMM's C operand
+            N, C, H, W = x.shape
+            h = F.conv2d(a, self.conv2.weight, self.conv2.bias + sc.bias, padding=1)
+            cout = h.shape[1]
+            w = sc.weight.view(1, cout, C).expand(N, -1, -1)
+            return torch.baddbmm(h.view(N, cout, H * W), w, x.view(N, C, H * W)).view(N, cout, H, W)
+        h = self.conv2(a)
+        return (x if sc is None else sc(x)) + h
 
 
 class Attention(nn.Module):

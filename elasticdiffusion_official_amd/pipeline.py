@@ -229,13 +229,21 @@ class ElasticDiffusion(nn.Module):
             coef = torch.tensor([self.scheduler.add_noise_coefficients(t) for t in timesteps], dtype=torch.float32,
                                 device=self.device)
             chunk = max(1, min(T, (64 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
-            for a in range(0, T, chunk):
-                b = min(T, a + chunk)
-                img = colour[a:b, :, None, None].expand(b - a, 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
-                dist = self.vae.encode(img).latent_dist
-                enc = (dist.mean.float() + dist.std.float() * post[a:b]) * sf
-                noised = coef[a:b, 0].view(-1, 1, 1, 1) * enc + coef[a:b, 1].view(-1, 1, 1, 1) * fwd[a:b]
-                frames[a:b, :, y0:y0 + Hs, x0:x0 + Ws] = noised
+
+            def encode(ix, *_):
+                """Noised strips of the timesteps ``ix`` (the VAE encodes are sharded over ranks like model rows)."""
+                outs = []
+                for a in range(0, ix.numel(), chunk):
+                    sel = ix[a:a + chunk]
+                    img = colour[sel][:, :, None, None].expand(sel.numel(), 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
+                    dist = self.vae.encode(img).latent_dist
+                    enc = (dist.mean.float() + dist.std.float() * post[sel]) * sf
+                    cf = coef[sel]
+                    outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
+                return torch.cat(outs)
+
+            strips = self.sharder.run(encode, torch.arange(T, device=self.device), None, None, None)
+            frames[:, :, y0:y0 + Hs, x0:x0 + Ws] = strips
         if self.cache_backgrounds:
             self._frame_cache[key] = frames
         return frames

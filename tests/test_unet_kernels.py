@@ -83,8 +83,8 @@ def test_unet_fused_vs_unfused_close():
     with torch.no_grad():
         M.FUSED_KERNELS = True
         a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
-        M.FUSED_KERNELS = False
+        M.FUSED_KERNELS = M.SHORTCUT_AS_GEMM = False
         b = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
-        M.FUSED_KERNELS = True
+        M.FUSED_KERNELS = M.SHORTCUT_AS_GEMM = True
     rel = float((a - b).norm() / b.norm())
     assert a.is_contiguous() and rel < 2e-2, rel
