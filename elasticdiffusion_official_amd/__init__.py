@@ -23,7 +23,7 @@ from .schedule import ConstScheduler, CosineScheduler, DDIMSchedule, LinearSched
 
 
 def __getattr__(name):  # lazy: importing the package must not require a GPU (build check, CPU host-logic tests)
-    if name == "ElasticDiffusion":
-        from .pipeline import ElasticDiffusion
-        return ElasticDiffusion
+    if name in ("ElasticDiffusion", "ElasticDiffusionControlNet"):
+        from . import pipeline
+        return getattr(pipeline, name)
     raise AttributeError(name)

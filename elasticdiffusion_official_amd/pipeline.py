@@ -515,3 +515,58 @@ class ElasticDiffusion(nn.Module):
         from PIL import Image
         arr = imgs.mul(255).byte().permute(0, 2, 3, 1).cpu().numpy()  # what ToPILImage does for float CHW (ED:1125)
         return [Image.fromarray(a) for a in arr], {}
+
+
+class ElasticDiffusionControlNet(ElasticDiffusion):
+    """Drop-in for the ControlNet variant (/root/reference/elastic_diffusion_w_controlnet.py:118-196, 1119-1322):
+    ``controlnet_model`` is the third positional constructor argument and ``condition_image`` /
+    ``controlnet_conditioning_scale`` sit where the reference has them in ``generate_image``.
+
+    ``condition_image`` is the already pre-processed condition (float tensor (1,3,8h,8w) in [0,1] at the reduced
+    resolution, EDC:1183-1193; a PIL image / numpy array of that size is converted).  The canny / depth extraction of
+    ``process_condition_image`` (EDC:1102-1117: cv2 / a HF depth pipeline) is pre-processing outside the loop and out
+    of scope; ``process_condition_image`` raises with that explanation."""
+
+    def __init__(self, device, sd_version="2.0", controlnet_model="canny", verbose=False, log_freq=5,
+                 view_batch_size=1, low_vram=False, *, controlnet=None, **kw):
+        if controlnet is None:
+            from .models import build_models
+            dev = torch.device(device)
+            unet, vae, controlnet = build_models(sd_version, device=dev, dtype=kw.get("model_dtype"), controlnet=True,
+                                                 weights=kw.get("weights"))
+            kw.setdefault("unet", unet)
+            kw.setdefault("vae", vae)
+        super().__init__(device, sd_version, verbose, log_freq, view_batch_size, low_vram, controlnet=controlnet, **kw)
+        self.controlnet_model = controlnet_model
+
+    def process_condition_image(self, condition_image, controlnet_model):
+        raise NotImplementedError("canny / depth extraction (EDC:1102-1117) is pre-processing outside the hot path; "
+                                  "pass the processed condition image to generate_image")
+
+    def _to_condition_tensor(self, image, h_px, w_px):
+        if isinstance(image, torch.Tensor):
+            t = image.float()
+            t = t[None] if t.dim() == 3 else t
+        else:  # PIL image or HWC uint8 array -> what VaeImageProcessor.preprocess(do_normalize=False) yields
+            arr = np.asarray(image.convert("RGB") if hasattr(image, "convert") else image)
+            t = torch.from_numpy(arr).float().div(255.0).permute(2, 0, 1)[None]
+        if tuple(t.shape[-2:]) != (h_px, w_px):
+            t = torch.nn.functional.interpolate(t, size=(h_px, w_px), mode="bilinear", align_corners=False)
+        return t
+
+    @torch.no_grad()
+    def generate_image(self, prompts, negative_prompts="", condition_image=None, height=768, width=768,
+                       num_inference_steps=50, guidance_scale=10.0, controlnet_conditioning_scale=1.0,
+                       resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
+                       rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
+                       progress=_identity_progress, tiled_decoder=False, grid=False, *, output_type="pil"):
+        if condition_image is None:
+            raise ValueError("condition_image is required (EDC:1183-1193)")
+        h, w = self.get_downsample_size(height, width)
+        s = self.vae_scale_factor
+        cond = self._to_condition_tensor(condition_image, h * s, w * s)
+        return super().generate_image(prompts, negative_prompts, height, width, num_inference_steps, guidance_scale,
+                                      resampling_steps, new_p, rrg_stop_t, rrg_init_weight, rrg_scherduler_cls,
+                                      cosine_scale, repaint_sampling, progress, tiled_decoder, grid,
+                                      condition_image=cond, controlnet_conditioning_scale=controlnet_conditioning_scale,
+                                      output_type=output_type)
