@@ -263,8 +263,17 @@ def main():
         if kern:
             dom = max(kern, key=lambda k: kern[k]["est_total_ms"])
             a = kern[dom]["gbs"]
+            traffic = None
+            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_glue_pmc.json")))["kernels"]
+                if args.workload == "sdxl_1024x2048" and dom in pmc:
+                    traffic = pmc[dom]["hbm_bytes_corrected"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/r1_glue_pmc.json (rocprofv3 --pmc, offline)",
+                    "algorithmic_bytes_per_launch": kern[dom]["alg_bytes"],
                     "us_per_launch": kern[dom]["us_per_launch"],
                     "note": "hand-written glue kernel with the largest total time in the timed region; duration = HIP "
                             "events around 200 back-to-back launches at the workload's shapes; tensors are <= 11 MiB "

@@ -55,7 +55,9 @@ class GraphedForward:
                 self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread polls events while we capture; in "global" mode that would invalidate
+        # the capture on multi-GPU runs
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             ent["out"] = self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
         ent["graph"] = graph
 

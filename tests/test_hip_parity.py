@@ -332,3 +332,44 @@ def test_cpu_device_is_rejected():
     from elasticdiffusion_official_amd import ElasticDiffusion
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ElasticDiffusion(torch.device("cpu"), "1.5", unet=FakeUNet(64), vae=FakeVAE())
+
+
+def _embed_fn_batch(B, xl=False):
+    (un, pun), (co, pco) = synthetic_text_embeds(B, xl=xl)
+    state = {"n": 0}
+
+    def fn(_):
+        state["n"] += 1
+        return (un, pun) if state["n"] % 2 == 1 else (co, pco)
+
+    return fn
+
+
+@pytest.mark.parametrize("sd,sample,H,W,B,R,patch", [
+    ("1.5", 64, 512, 768, 2, 1, None),      # batch of two prompts: rows are (view, prompt) ordered
+    ("1.5", 64, 256, 512, 1, 2, None),      # latent 32x64: one dimension smaller than the model -> padded VIEWS too
+    ("1.5", 64, 1080, 1920, 1, 1, None),    # windows do not tile: overlapping centres, fractional reduction 135 -> 36
+    ("XL1.0", 128, 1024, 1536, 2, 1, 96),   # SDXL geometry, custom patch size, two prompts
+])
+def test_edge_geometries_and_prompt_batches_vs_oracle(sd, sample, H, W, B, R, patch):
+    """No golden for these: the oracle runs on the CPU in the test (seconds).  rel-L2 < 1e-4, identical RNG end state."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    xl = sd.startswith("XL")
+    kw = dict(height=H, width=W, num_inference_steps=2, guidance_scale=10.0, resampling_steps=R, new_p=0.3,
+              rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0, repaint_sampling=True)
+    prompts = ["p%d" % i for i in range(B)]
+    pipe = ElasticDiffusion(DEV, sd, view_batch_size=3, unet=FakeUNet(sample, xl=xl), vae=FakeVAE(),
+                            text_encoder=_embed_fn_batch(B, xl))
+    orc = eo.ElasticOracle(FakeUNet(sample, xl=xl), FakeVAE(), DDIMOracle(), _embed_fn_batch(B, xl), sd_version=sd,
+                           view_batch_size=3, pooled_dim=16 if xl else None)
+    if patch is not None:
+        pipe.set_view_config(patch)
+        orc.set_view_config(patch)
+    pipe.seed_everything(5)
+    z = pipe.generate_latents(prompts, "", **kw).cpu()
+    tail = torch.rand(3)
+    orc.seed_everything(5)
+    want = orc.generate_latent(prompts, "", **kw)
+    assert z.shape == want.shape == (B, 4, H // 8, W // 8)
+    assert rel_l2(z, want) < 1e-4, rel_l2(z, want)
+    assert torch.equal(tail, torch.rand(3))
