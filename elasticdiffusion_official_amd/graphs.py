@@ -9,18 +9,28 @@ Static buffers: a hipGraph replays fixed addresses, so each captured shape owns 
 timestep, text / pooled / condition rows) and its output tensor.  The assemble kernels write the model rows straight
 into the static input (``input_rows``), so no extra copy is added to the hot loop; side inputs are copied once per image.
 """
+import gc
 import warnings
+import weakref
 
 import torch
 
 
 class GraphedForward:
     def __init__(self, fwd, enabled=True, warmup_iters=2):
-        self.fwd = fwd
+        # a bound method would make pipeline <-> runner a reference cycle that only the cyclic GC can free -- and a
+        # hipGraph being destroyed by a GC pass that happens to run *during another capture* aborts the process
+        self._fwd_ref = weakref.WeakMethod(fwd) if hasattr(fwd, "__self__") else (lambda: fwd)
         self.enabled = enabled and torch.cuda.is_available()
         self.warmup_iters = warmup_iters
         self.entries = {}
         self.epoch = 0
+
+    def fwd(self, *a):
+        f = self._fwd_ref()
+        if f is None:
+            raise RuntimeError("the pipeline that owns this GraphedForward is gone")
+        return f(*a)
 
     def new_image(self):
         """Side inputs (text / pooled / condition rows) may have changed: re-copy them on next use."""
@@ -55,10 +65,19 @@ class GraphedForward:
                 self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread polls events while we capture; in "global" mode that would invalidate
-        # the capture on multi-GPU runs
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            ent["out"] = self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
+        # No Python GC pass may run while the stream is capturing: collecting an old pipeline's hipGraph / memory pool
+        # there calls HIP APIs that are illegal during capture and aborts the process (seen on the MI355X box).
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            # thread_local: the RCCL watchdog thread polls events while we capture; in "global" mode that would
+            # invalidate the capture on multi-GPU runs
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                ent["out"] = self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         ent["graph"] = graph
 
     def __call__(self, x, t, text=None, pooled=None, cond=None):
