@@ -1,0 +1,38 @@
+"""CPU: bench.py's bookkeeping (the driver depends on its contract) and the CLI's argument surface."""
+import subprocess
+import sys
+
+import bench
+
+
+def test_forward_sample_counts_match_baseline_md():
+    # (T-1)[2(R+1)+V+(2+V)(R>0)] + [2(R+1)+V]
+    assert bench.forward_samples(10, 0, 1) == 30            # cfg1
+    assert bench.forward_samples(50, 7, 4) == 1294          # cfg2 / cfg3 / cfg5
+    assert bench.forward_samples(50, 7, 16) == 2482         # cfg4, R = 7
+    assert bench.forward_samples(50, 10, 16) == 2782        # cfg4, R = 10
+
+
+def test_algorithmic_bytes_table():
+    geo = dict(B=1, C=4, Hl=128, Wl=256, h=64, w=128, d=128, K=8, V=4, n_sub=20, mb=2)
+    L, l = 4 * 128 * 256 * 4, 4 * 64 * 128 * 4
+    assert bench.algorithmic_bytes("ed_undo_step", geo) == 22 * L
+    assert bench.algorithmic_bytes("ed_cfg_ddim_step", geo) == 5 * L
+    assert bench.algorithmic_bytes("ed_rrg_update", geo) == 3 * L + 3 * l
+    assert bench.algorithmic_bytes("ed_pick_assemble", geo)(8) == 8 * (l + 64 * 128) + 16 * 4 * 128 * 128 * 2 + 8 * l
+    assert set(bench.WORKLOADS) >= {"sdxl_1024x2048", "sd15_512x1024", "sdxl_2048x2048_tiled"}
+    wl = bench.WORKLOADS["sdxl_1024x2048"]
+    assert (wl["H"], wl["W"], wl["vbs"], wl["R"]) == (1024, 2048, 16, 7)
+
+
+def test_unet_flop_count_is_stable():
+    import torch
+    f = bench.unet_flops_per_sample("sdxl", torch.bfloat16)
+    assert abs(f - 6.761e12) / 6.761e12 < 1e-3
+    assert abs(bench.unet_flops_per_sample("sd15", torch.bfloat16) - 0.8033e12) / 0.8033e12 < 1e-3
+
+
+def test_bench_and_cli_help_run_without_gpu():
+    for cmd in ([sys.executable, "bench.py", "--help"], [sys.executable, "-m", "elasticdiffusion_official_amd", "--help"]):
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=bench.ROOT)
+        assert out.returncode == 0 and "--" in out.stdout, out.stderr
