@@ -166,6 +166,115 @@ k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
   }
 }
 
+
+// ---- GroupNorm (+SiLU) over channels-last activations [N, HW, C] ------------------------------------
+// Three small launches: (1) per-block partial sums per group, (2) finalise mean / rstd in double, (3) vectorised apply.
+// Reads 2x, writes 1x -- same traffic as the NCHW kernel -- but every access is a full 16-byte channel vector, and the
+// output *is* the transformer's token layout (no permute copy) and the layout MIOpen's CK convolutions consume.
+#define GNL_THREADS 256
+
+template <typename T>
+__global__ void __launch_bounds__(GNL_THREADS)
+k_gn_nhwc_partial(const uint16_t* __restrict__ x, float* __restrict__ partial, int C, int HW, int G, int rows_per_block) {
+  // block (n, chunk): rows [chunk*rows_per_block, ...) of sample n; thread t walks (row, vec8) pairs with stride 256
+  extern __shared__ float sh[];  // [G*2] group sums
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int VC = C >> 3, cpg = C / G;
+  for (int i = threadIdx.x; i < 2 * G; i += GNL_THREADS) sh[i] = 0.f;
+  __syncthreads();
+  int r0 = chunk * rows_per_block;
+  int r1 = min(HW, r0 + rows_per_block);
+  const uint16_t* base = x + (int64_t)n * HW * C;
+  int64_t total = (int64_t)(r1 - r0) * VC;
+  // a thread's successive items advance by 256 vectors; when VC divides 256 (or vice versa) it keeps the same
+  // channels, in general it does not, so sums are binned per item into at most two groups
+  float acc_s[2] = {0.f, 0.f}, acc_q[2] = {0.f, 0.f};
+  int acc_g = -1;
+  for (int64_t it = threadIdx.x; it < total; it += GNL_THREADS) {
+    int row = r0 + (int)(it / VC);
+    int vc = (int)(it % VC);
+    int c0 = vc << 3;
+    U16x8 v = *reinterpret_cast<const U16x8*>(base + (int64_t)row * C + c0);
+    int g0 = c0 / cpg;
+    if (g0 != acc_g) {  // flush the accumulators when the thread moves to other channels
+      if (acc_g >= 0) {
+        atomicAdd(&sh[2 * acc_g], acc_s[0]);
+        atomicAdd(&sh[2 * acc_g + 1], acc_q[0]);
+        if (acc_g + 1 < G && (acc_s[1] != 0.f || acc_q[1] != 0.f)) {
+          atomicAdd(&sh[2 * (acc_g + 1)], acc_s[1]);
+          atomicAdd(&sh[2 * (acc_g + 1) + 1], acc_q[1]);
+        }
+      }
+      acc_g = g0;
+      acc_s[0] = acc_s[1] = acc_q[0] = acc_q[1] = 0.f;
+    }
+    int split = (g0 + 1) * cpg - c0;  // channels [0, split) of this vector belong to g0, the rest to g0+1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = T::to_f32(v.v[e]);
+      int k = e < split ? 0 : 1;
+      acc_s[k] += f;
+      acc_q[k] += f * f;
+    }
+  }
+  if (acc_g >= 0) {
+    atomicAdd(&sh[2 * acc_g], acc_s[0]);
+    atomicAdd(&sh[2 * acc_g + 1], acc_q[0]);
+    if (acc_g + 1 < G && (acc_s[1] != 0.f || acc_q[1] != 0.f)) {
+      atomicAdd(&sh[2 * (acc_g + 1)], acc_s[1]);
+      atomicAdd(&sh[2 * (acc_g + 1) + 1], acc_q[1]);
+    }
+  }
+  __syncthreads();
+  float* dst = partial + ((int64_t)n * gridDim.x + chunk) * 2 * G;
+  for (int i = threadIdx.x; i < 2 * G; i += GNL_THREADS) dst[i] = sh[i];
+}
+
+__global__ void k_gn_nhwc_finalize(const float* __restrict__ partial, float* __restrict__ stats, int G, int nchunks,
+                                   double count, float eps, int NG) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, g)
+  if (t >= NG) return;
+  int n = t / G, g = t % G;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* p = partial + ((int64_t)n * nchunks + c) * 2 * G + 2 * g;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[2 * t] = (float)mean;
+  stats[2 * t + 1] = rsqrtf((float)var + eps);
+}
+
+template <typename T, bool ACT>
+__global__ void __launch_bounds__(GNL_THREADS)
+k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                const float* __restrict__ stats, uint16_t* __restrict__ out, int C, int HW, int G, int64_t total_vec) {
+  const int VC = C >> 3, cpg = C / G;
+  for (int64_t t = (int64_t)blockIdx.x * GNL_THREADS + threadIdx.x; t < total_vec; t += (int64_t)gridDim.x * GNL_THREADS) {
+    int vc = (int)(t % VC);
+    int64_t np = t / VC;
+    int n = (int)(np / HW);
+    int c0 = vc << 3;
+    U16x8 v = *reinterpret_cast<const U16x8*>(x + t * 8);
+    U16x8 gm = *reinterpret_cast<const U16x8*>(gamma + c0);
+    U16x8 bt = *reinterpret_cast<const U16x8*>(beta + c0);
+    U16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int g = (c0 + e) / cpg;
+      float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+      float a = rstd * T::to_f32(gm.v[e]);
+      float b = fmaf(-a, mean, T::to_f32(bt.v[e]));
+      float y = T::to_f32(T::from_f32(fmaf(a, T::to_f32(v.v[e]), b)));
+      o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+    }
+    *reinterpret_cast<U16x8*>(out + t * 8) = o;
+  }
+}
+
 inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -210,6 +319,50 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, 
 #undef GN_DISPATCH
 #undef GN_LAUNCH
   return done();
+}
+
+int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
+                      int C, int HW, int G, float eps, int act_silu, void* stream) {
+  if (N == 0) return 0;
+  if (C % G != 0 || C % 8 != 0 || G > 256 || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  // ~64 K elements per partial block keeps >= 256 blocks in flight for every UNet shape at batch >= 3
+  int rows_per_block = (65536 + C - 1) / C;
+  if (rows_per_block < 1) rows_per_block = 1;
+  int nchunks = (HW + rows_per_block - 1) / rows_per_block;
+  float* partial = workspace;                                // [N, nchunks, G, 2]
+  float* stats = workspace + (int64_t)N * nchunks * G * 2;   // [N, G, 2]
+  dim3 grid1(nchunks, N);
+  size_t lds = sizeof(float) * 2 * G;
+  int64_t total_vec = (int64_t)N * HW * (C / 8);
+  int grid3 = (int)((total_vec + GNL_THREADS - 1) / GNL_THREADS < 8192 ? (total_vec + GNL_THREADS - 1) / GNL_THREADS : 8192);
+  int NG = N * G;
+#define GNL_RUN(T)                                                                                                     \
+  k_gn_nhwc_partial<T><<<grid1, GNL_THREADS, lds, s>>>((const uint16_t*)x, partial, C, HW, G, rows_per_block);         \
+  k_gn_nhwc_finalize<<<(NG + 127) / 128, 128, 0, s>>>(partial, stats, G, nchunks, (double)HW * (C / G), eps, NG);      \
+  if (act_silu)                                                                                                        \
+    k_gn_nhwc_apply<T, true><<<grid3, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
+                                                          (const uint16_t*)beta, stats, (uint16_t*)out, C, HW, G, total_vec); \
+  else                                                                                                                 \
+    k_gn_nhwc_apply<T, false><<<grid3, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                \
+                                                           (const uint16_t*)beta, stats, (uint16_t*)out, C, HW, G, total_vec);
+  if (dtype == ED_BF16) {
+    GNL_RUN(BF16)
+  } else if (dtype == ED_F16) {
+    GNL_RUN(F16)
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+#undef GNL_RUN
+  return done();
+}
+
+int64_t ed_groupnorm_nhwc_workspace(int N, int C, int HW, int G) {
+  int rows_per_block = (65536 + C - 1) / C;
+  if (rows_per_block < 1) rows_per_block = 1;
+  int nchunks = (HW + rows_per_block - 1) / rows_per_block;
+  return ((int64_t)N * nchunks * G * 2 + (int64_t)N * G * 2) * (int64_t)sizeof(float);
 }
 
 }  // extern "C"

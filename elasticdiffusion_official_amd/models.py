@@ -25,14 +25,29 @@ import torch.nn.functional as F
 FUSED_KERNELS = True
 
 
+# Channels-last activations end to end (MIOpen's CK convolutions are NHWC; NCHW costs a transpose around every conv,
+# 2.4 % of GPU time in profiles/r1_bench_sdxl_1024x2048_kernel_stats_final.csv).  Off until the NHWC convolution shapes
+# have been through a MIOpen find pass and the end-to-end A/B is measured.
+CHANNELS_LAST = False
+
+
 def _fusable(x):
     return FUSED_KERNELS and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
 
 
+def _fusable_nhwc(x):
+    return (FUSED_KERNELS and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
+
+
 def group_norm_act(norm, x, silu=False, tokens=False):
-    """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout].  HIP: ed_groupnorm (one launch); torch otherwise."""
+    """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout].  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
     N, C, H, W = x.shape
     cpg = C // norm.num_groups
+    if _fusable_nhwc(x) and C % 8 == 0:
+        from . import ops
+        y = ops.groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
+        return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y  # a view: NHWC memory is the token layout
     if _fusable(x) and (H * W) % 8 == 0 and (not tokens or cpg % 4 == 0):
         from . import ops
         return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, tokens=tokens)
@@ -328,6 +343,8 @@ class UNet2DConditionModel(nn.Module):
     def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
         x = sample.to(self.dtype)
+        if CHANNELS_LAST:
+            x = x.contiguous(memory_format=torch.channels_last)
         ctx = encoder_hidden_states.to(self.dtype)
         emb = self.embed(x, timestep, added_cond_kwargs)
         x = self.conv_in(x)
@@ -601,5 +618,7 @@ def build_models(sd_version, device="cuda", dtype=None, weights=None, vae_dtype=
         else:
             _seeded_init(m, seed + k)
         m = m.to(dtype=dt).eval().requires_grad_(False)  # NCHW: measured 5 % faster than channels_last end to end
+        if CHANNELS_LAST and sub != "vae":
+            m = m.to(memory_format=torch.channels_last)
         out.append(m)
     return tuple(out)

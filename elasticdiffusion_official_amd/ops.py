@@ -240,3 +240,18 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False):
     _call("ed_groupnorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
           _dev(out, None, "out"), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), int(tokens), _stream())
     return out
+
+
+def groupnorm_nhwc(x, gamma, beta, groups, eps, silu=False):
+    """x [N,C,H,W] in torch.channels_last memory format (16-bit) -> GroupNorm(+SiLU), same format."""
+    N, C, H, W = x.shape
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("x must be channels_last")
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    nbytes = _hip.lib().ed_groupnorm_nhwc_workspace(N, C, H * W, groups)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    if not x.is_cuda:
+        raise RuntimeError("x must be a tensor on the MI355X; no CPU fallback")
+    _call("ed_groupnorm_nhwc", x.data_ptr(), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"), out.data_ptr(),
+          ws.data_ptr(), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), _stream())
+    return out

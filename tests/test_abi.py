@@ -11,7 +11,7 @@ from elasticdiffusion_official_amd import _hip
 def header_functions():
     text = open(os.path.join(_hip.INCLUDE, "elastic_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return re.findall(r"\b(?:int|const char\*)\s+(ed_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    return re.findall(r"\b(?:int64_t|int|const char\*)\s+(ed_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
 
 
 def test_library_builds_and_exports_every_declared_symbol():

@@ -68,6 +68,57 @@ def test_groupnorm(dtype, N, C, H, W, silu, tokens):
     assert float((got == want).float().mean()) > 0.5        # and mostly bit-identical to it
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 640, 16, 16), (2, 1280, 8, 8), (1, 960, 64, 64), (2, 1920, 16, 16),
+                                     (1, 2560, 8, 8), (2, 32, 4, 2)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_channels_last(dtype, N, C, H, W, silu):
+    """ed_groupnorm_nhwc: channels-last in / out, vectors straddling group boundaries (cpg = 10, 20, 30, 60, 1)."""
+    from elasticdiffusion_official_amd import ops
+    x = (torch.randn(N, C, H, W, device=DEV) * 1.7 + 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (1 + 0.2 * torch.randn(C, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(C, device=DEV)).to(dtype)
+    got = ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=silu)
+    assert got.shape == x.shape and got.is_contiguous(memory_format=torch.channels_last)
+    ref = F.group_norm(x.float(), 32, w.float(), b.float(), 1e-5)
+    want = F.group_norm(x.contiguous(), 32, w, b, 1e-5)
+    if silu:
+        ref, want = F.silu(ref), F.silu(want)
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    err = (got.float() - ref).abs()
+    assert bool((err <= 2.0 * ulp * ref.abs() + 4 * ulp).all()), float(err.max())
+    rel = float((got.float() - ref).norm() / ref.norm())
+    rel_torch = float((want.float() - ref).norm() / ref.norm())
+    assert rel < 1.5 * rel_torch + 1e-6, (rel, rel_torch)
+    # token view of the result == permute of the NCHW result
+    tok = got.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    assert tok.data_ptr() == got.data_ptr()
+
+
+def test_unet_channels_last_path_close():
+    """The whole (small) UNet with channels-last activations + NHWC GroupNorm vs the default NCHW path."""
+    from elasticdiffusion_official_amd import models as M
+    cfg = dict(M.UNET_CONFIGS["sdxl"])
+    cfg.update(block_out_channels=(64, 128, 256), heads=(1, 2, 4), transformer_depth=(1, 1, 2), cross_attention_dim=64,
+               addition_time_embed_dim=8, pooled_projection_dim=16, sample_size=32)
+    torch.manual_seed(0)
+    u = M.UNet2DConditionModel(**cfg).to(DEV, torch.bfloat16).eval()
+    x = torch.randn(3, 4, 32, 32, device=DEV, dtype=torch.bfloat16)
+    e = torch.randn(3, 77, 64, device=DEV, dtype=torch.bfloat16)
+    kw = {"text_embeds": torch.randn(3, 16, device=DEV, dtype=torch.bfloat16), "time_ids": torch.zeros(3, 6, device=DEV)}
+    t = torch.tensor(500, device=DEV)
+    with torch.no_grad():
+        a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+        try:
+            M.CHANNELS_LAST = True
+            ucl = u.to(memory_format=torch.channels_last)
+            b = ucl(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+        finally:
+            M.CHANNELS_LAST = False
+    rel = float((a - b).norm() / a.norm())
+    assert rel < 2e-2, rel
+
+
 def test_unet_fused_vs_unfused_close():
     """Whole (small) UNet in bf16 with and without the fused kernels: same output up to bf16 noise."""
     from elasticdiffusion_official_amd import models as M
