@@ -324,7 +324,9 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, 
 int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
                       int C, int HW, int G, float eps, int act_silu, void* stream) {
   if (N == 0) return 0;
-  if (C % G != 0 || C % 8 != 0 || G > 256 || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
+  // C/G >= 8: an 8-channel vector then touches at most two groups (what the partial-sum kernel bins into)
+  if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 ||
+      (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   // ~64 K elements per partial block keeps >= 256 blocks in flight for every UNet shape at batch >= 3

@@ -44,7 +44,7 @@ def group_norm_act(norm, x, silu=False, tokens=False):
     """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout].  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
     N, C, H, W = x.shape
     cpg = C // norm.num_groups
-    if _fusable_nhwc(x) and C % 8 == 0:
+    if _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8:
         from . import ops
         y = ops.groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
         return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y  # a view: NHWC memory is the token layout

@@ -194,7 +194,7 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, 
  * ed_groupnorm_nhwc -- the same GroupNorm [+ SiLU] for channels-last activations: x / out dtype [N, HW, C] (the memory
  * of an NCHW tensor in torch.channels_last format, which is also the transformer's token layout).  Three launches
  * (partial sums, finalise in double, vectorised apply); `workspace` is caller-owned fp32 scratch of
- * ed_groupnorm_nhwc_workspace(N, C, HW, G) bytes.  C % 8 == 0, C % G == 0, G <= 256; dtype = ED_F16 | ED_BF16.
+ * ed_groupnorm_nhwc_workspace(N, C, HW, G) bytes.  C % 8 == 0, C % G == 0, C / G >= 8, G <= 256; dtype = ED_F16 | ED_BF16.
  */
 int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
                       int C, int HW, int G, float eps, int act_silu, void* stream);

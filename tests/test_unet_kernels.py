@@ -70,7 +70,7 @@ def test_groupnorm(dtype, N, C, H, W, silu, tokens):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 640, 16, 16), (2, 1280, 8, 8), (1, 960, 64, 64), (2, 1920, 16, 16),
-                                     (1, 2560, 8, 8), (2, 32, 4, 2)])
+                                     (1, 2560, 8, 8), (2, 256, 4, 2)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_channels_last(dtype, N, C, H, W, silu):
     """ed_groupnorm_nhwc: channels-last in / out, vectors straddling group boundaries (cpg = 10, 20, 30, 60, 1)."""
@@ -99,7 +99,7 @@ def test_unet_channels_last_path_close():
     """The whole (small) UNet with channels-last activations + NHWC GroupNorm vs the default NCHW path."""
     from elasticdiffusion_official_amd import models as M
     cfg = dict(M.UNET_CONFIGS["sdxl"])
-    cfg.update(block_out_channels=(64, 128, 256), heads=(1, 2, 4), transformer_depth=(1, 1, 2), cross_attention_dim=64,
+    cfg.update(block_out_channels=(256, 320, 512), heads=(4, 5, 8), transformer_depth=(1, 1, 2), cross_attention_dim=64,
                addition_time_embed_dim=8, pooled_projection_dim=16, sample_size=32)
     torch.manual_seed(0)
     u = M.UNet2DConditionModel(**cfg).to(DEV, torch.bfloat16).eval()
@@ -117,6 +117,10 @@ def test_unet_channels_last_path_close():
             M.CHANNELS_LAST = False
     rel = float((a - b).norm() / a.norm())
     assert rel < 2e-2, rel
+    with pytest.raises(RuntimeError):  # channels-per-group < 8 is rejected by the C ABI, never silently wrong
+        from elasticdiffusion_official_amd import ops
+        xs = torch.randn(1, 32, 4, 4, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ops.groupnorm_nhwc(xs, torch.ones(32, device=DEV, dtype=torch.bfloat16), torch.zeros(32, device=DEV, dtype=torch.bfloat16), 32, 1e-5)
 
 
 def test_unet_fused_vs_unfused_close():
