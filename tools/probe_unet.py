@@ -21,10 +21,14 @@ if os.environ.get("ED_FUSED", "1") == "0":
     M.FUSED_KERNELS = False
 if os.environ.get("ED_SCGEMM", "1") == "0":
     M.SHORTCUT_AS_GEMM = False
+if os.environ.get("ED_CL", "0") == "1":
+    M.CHANNELS_LAST = True
 cfg = M.UNET_CONFIGS[fam]
 dt = torch.bfloat16
 torch.manual_seed(0)
 unet = M.UNet2DConditionModel(**cfg).to("cuda", dt).eval().requires_grad_(False)
+if M.CHANNELS_LAST:
+    unet = unet.to(memory_format=torch.channels_last)
 S = cfg["sample_size"]
 flops = {"sdxl": 6.761e12, "sd15": 0.803e12}[fam]
 for B in batches:
@@ -37,4 +41,4 @@ for B in batches:
     t0 = time.perf_counter()
     with torch.no_grad():
         dtm = bench(lambda: unet(x, t, encoder_hidden_states=e, added_cond_kwargs=kw))
-    print(f"{fam} fused={M.FUSED_KERNELS} scgemm={M.SHORTCUT_AS_GEMM} benchmark={torch.backends.cudnn.benchmark} B={B:2d}: {dtm*1e3:8.1f} ms  {dtm*1e3/B:7.1f} ms/sample  {B*flops/dtm/1e12:7.1f} TFLOP/s  (wall incl. first call {time.perf_counter()-t0:.1f}s)", flush=True)
+    print(f"{fam} cl={M.CHANNELS_LAST} fused={M.FUSED_KERNELS} scgemm={M.SHORTCUT_AS_GEMM} benchmark={torch.backends.cudnn.benchmark} B={B:2d}: {dtm*1e3:8.1f} ms  {dtm*1e3/B:7.1f} ms/sample  {B*flops/dtm/1e12:7.1f} TFLOP/s  (wall incl. first call {time.perf_counter()-t0:.1f}s)", flush=True)
