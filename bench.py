@@ -179,6 +179,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if os.environ.get("ED_DIST_BACKEND") == "gloo" and torch.cuda.device_count() == 1:
+        local_rank = 0  # rehearsal: all ranks share the only GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     g = args.shard_group or (2 if world >= 2 else 1)
@@ -187,7 +189,11 @@ def main():
     n_groups, group_id, pg = world // g, rank // g, False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ED_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N>1 logic on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         groups = [dist.new_group(ranks=list(range(i * g, (i + 1) * g))) for i in range(n_groups)]  # collective call
         pg = groups[group_id] if g > 1 else False
 
