@@ -291,7 +291,7 @@ def main():
             traffic = None
             try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_glue_pmc.json")))["kernels"]
-                if args.workload == "sdxl_1024x2048" and dom in pmc:
+                if args.workload == "sdxl_1024x2048" and T == 50 and dom in pmc:
                     traffic = pmc[dom]["hbm_bytes_corrected"]
             except (OSError, KeyError, ValueError):
                 pass
