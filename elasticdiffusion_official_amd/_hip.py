@@ -41,6 +41,7 @@ SIGNATURES = {
     "ed_tile_accumulate_normalise": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ed_geglu": [_vp, _vp, _i, _i64, _i, _vp],
     "ed_groupnorm": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ed_layernorm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
     "ed_groupnorm_nhwc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc_workspace": [_i, _i, _i, _i],
 }

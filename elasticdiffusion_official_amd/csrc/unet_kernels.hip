@@ -275,6 +275,70 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
   }
 }
 
+
+// ---- LayerNorm over the last dimension: one wavefront per row, values kept in registers ------------------
+// x / out [M, D] 16-bit, D % 8 == 0, D <= 64 lanes * 8 * LN_MAX_IT.  Two passes over registers (mean, then centred
+// variance): no E[x^2]-mean^2 cancellation, one global read and one global write per element.
+#define LN_MAX_IT 4
+#define LN_ROWS_PER_BLOCK 4
+
+template <typename T>
+__global__ void __launch_bounds__(64 * LN_ROWS_PER_BLOCK)
+k_layernorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+            uint16_t* __restrict__ out, int64_t M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int VC = D >> 3;
+  const uint16_t* xr = x + row * (int64_t)D;
+  float v[LN_MAX_IT][8];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < LN_MAX_IT; ++it) {
+    int vc = lane + it * 64;
+    if (vc < VC) {
+      U16x8 u = *reinterpret_cast<const U16x8*>(xr + (vc << 3));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[it][e] = T::to_f32(u.v[e]);
+        s += v[it][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < LN_MAX_IT; ++it) {
+    int vc = lane + it * 64;
+    if (vc < VC) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = v[it][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = rsqrtf(q / (float)D + eps);
+  uint16_t* orow = out + row * (int64_t)D;
+#pragma unroll
+  for (int it = 0; it < LN_MAX_IT; ++it) {
+    int vc = lane + it * 64;
+    if (vc < VC) {
+      U16x8 g = *reinterpret_cast<const U16x8*>(gamma + (vc << 3));
+      U16x8 b = *reinterpret_cast<const U16x8*>(beta + (vc << 3));
+      U16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o.v[e] = T::from_f32(fmaf(T::to_f32(g.v[e]), rstd * (v[it][e] - mean), T::to_f32(b.v[e])));
+      *reinterpret_cast<U16x8*>(orow + (vc << 3)) = o;
+    }
+  }
+}
+
 inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -357,6 +421,27 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* 
     return (int)hipErrorInvalidValue;
   }
 #undef GNL_RUN
+  return done();
+}
+
+int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
+                 void* stream) {
+  if (M == 0) return 0;
+  if (D % 8 != 0 || D > 64 * 8 * LN_MAX_IT ||
+      (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
+    return (int)hipErrorInvalidValue;
+  int64_t blocks = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+  if (blocks > 0x7fffffff) return (int)hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks), block(64 * LN_ROWS_PER_BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ED_BF16)
+    k_layernorm<BF16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta,
+                                            (uint16_t*)out, M, D, eps);
+  else if (dtype == ED_F16)
+    k_layernorm<F16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta,
+                                           (uint16_t*)out, M, D, eps);
+  else
+    return (int)hipErrorInvalidValue;
   return done();
 }
 

@@ -57,6 +57,18 @@ def group_norm_act(norm, x, silu=False, tokens=False):
     return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y
 
 
+FUSED_LAYERNORM = True
+
+
+def layer_norm(norm, x):
+    """LayerNorm over the last dim.  HIP: ed_layernorm (one wave per row); torch otherwise."""
+    D = x.shape[-1]
+    if FUSED_LAYERNORM and _fusable(x) and D % 8 == 0 and D <= 2048 and norm.elementwise_affine:
+        from . import ops
+        return ops.layernorm(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
 class ModelOutput(dict):
     """``out['sample']`` and ``out.sample`` (the reference indexes the former, ED:422)."""
 
@@ -171,9 +183,9 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context) + x
-        return self.ff(self.norm3(x)) + x
+        x = self.attn1(layer_norm(self.norm1, x)) + x
+        x = self.attn2(layer_norm(self.norm2, x), context) + x
+        return self.ff(layer_norm(self.norm3, x)) + x
 
 
 class Transformer2DModel(nn.Module):

@@ -255,3 +255,12 @@ def groupnorm_nhwc(x, gamma, beta, groups, eps, silu=False):
     _call("ed_groupnorm_nhwc", x.data_ptr(), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"), out.data_ptr(),
           ws.data_ptr(), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), _stream())
     return out
+
+
+def layernorm(x, gamma, beta, eps):
+    """x [..., D] contiguous 16-bit -> LayerNorm over D."""
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    _call("ed_layernorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
+          _dev(out, None, "out"), _code(x, "x"), x.numel() // D, D, float(eps), _stream())
+    return out

@@ -191,6 +191,14 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, 
                  float eps, int act_silu, int tokens_out, void* stream);
 
 /*
+ * ed_layernorm -- LayerNorm over the last dimension of [M, D] 16-bit activations (BasicTransformerBlock.norm1/2/3):
+ * one wavefront per row, two passes over registers (mean, centred variance), one read + one write per element.
+ *   D % 8 == 0, D <= 2048; gamma / beta dtype [D]; dtype = ED_F16 | ED_BF16.
+ */
+int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
+                 void* stream);
+
+/*
  * ed_groupnorm_nhwc -- the same GroupNorm [+ SiLU] for channels-last activations: x / out dtype [N, HW, C] (the memory
  * of an NCHW tensor in torch.channels_last format, which is also the transformer's token layout).  Three launches
  * (partial sums, finalise in double, vectorised apply); `workspace` is caller-owned fp32 scratch of

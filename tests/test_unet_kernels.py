@@ -69,6 +69,26 @@ def test_groupnorm(dtype, N, C, H, W, silu, tokens):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,D", [(4096, 640), (1000, 1280), (77, 2048), (5, 8), (3, 320)])
+def test_layernorm(dtype, M, D):
+    from elasticdiffusion_official_amd import ops
+    x = (torch.randn(M, D, device=DEV) * 2.1 + 0.4).to(dtype)
+    w = (1 + 0.2 * torch.randn(D, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(D, device=DEV)).to(dtype)
+    got = ops.layernorm(x, w, b, 1e-5)
+    ref = F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    want = F.layer_norm(x, (D,), w, b, 1e-5)
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    err = (got.float() - ref).abs()
+    assert bool((err <= 1.0 * ulp * ref.abs() + 2 * ulp).all()), float(err.max())  # single rounding: within 1 ulp of fp32
+    rel = float((got.float() - ref).norm() / ref.norm())
+    rel_torch = float((want.float() - ref).norm() / ref.norm())
+    assert rel < 1.2 * rel_torch + 1e-6, (rel, rel_torch)
+    got3 = ops.layernorm(x.view(1, M, D), w, b, 1e-5)
+    assert torch.equal(got3.view(M, D), got)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 640, 16, 16), (2, 1280, 8, 8), (1, 960, 64, 64), (2, 1920, 16, 16),
                                      (1, 2560, 8, 8), (2, 256, 4, 2)])
 @pytest.mark.parametrize("silu", [True, False])

@@ -19,6 +19,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "find":
     torch.backends.cudnn.benchmark = True
 if os.environ.get("ED_FUSED", "1") == "0":
     M.FUSED_KERNELS = False
+if os.environ.get("ED_LN", "1") == "0":
+    M.FUSED_LAYERNORM = False
 if os.environ.get("ED_SCGEMM", "1") == "0":
     M.SHORTCUT_AS_GEMM = False
 if os.environ.get("ED_CL", "0") == "1":
@@ -41,4 +43,4 @@ for B in batches:
     t0 = time.perf_counter()
     with torch.no_grad():
         dtm = bench(lambda: unet(x, t, encoder_hidden_states=e, added_cond_kwargs=kw))
-    print(f"{fam} cl={M.CHANNELS_LAST} fused={M.FUSED_KERNELS} scgemm={M.SHORTCUT_AS_GEMM} benchmark={torch.backends.cudnn.benchmark} B={B:2d}: {dtm*1e3:8.1f} ms  {dtm*1e3/B:7.1f} ms/sample  {B*flops/dtm/1e12:7.1f} TFLOP/s  (wall incl. first call {time.perf_counter()-t0:.1f}s)", flush=True)
+    print(f"{fam} cl={M.CHANNELS_LAST} ln={M.FUSED_LAYERNORM} fused={M.FUSED_KERNELS} scgemm={M.SHORTCUT_AS_GEMM} benchmark={torch.backends.cudnn.benchmark} B={B:2d}: {dtm*1e3:8.1f} ms  {dtm*1e3/B:7.1f} ms/sample  {B*flops/dtm/1e12:7.1f} TFLOP/s  (wall incl. first call {time.perf_counter()-t0:.1f}s)", flush=True)
