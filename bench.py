@@ -440,7 +440,7 @@ def cpu_baseline(pipe, wl, T, fs, V):
     return {"value": round(1.0 / sec_img, 8), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 of {fs} fp32 UNet forward-samples ({t_sample:.2f} s{scaled}) + oracle glue of 1 of {T} timesteps "
                       f"({t_glue:.2f} s, zero-cost UNet), extrapolated: {fs}*t_sample + {T}*t_glue = {sec_img:.0f} s/image; "
-                      "VAE decode excluded",
+                      "the reference's 898 pad-strip VAE encodes and the VAE decode are excluded (favours the CPU)",
             "t_forward_sample_s": round(t_sample, 3), "t_glue_step_s": round(t_glue, 3)}
 
 

@@ -549,9 +549,15 @@ class ElasticDiffusionControlNet(ElasticDiffusion):
         if isinstance(image, torch.Tensor):
             t = image.float()
             t = t[None] if t.dim() == 3 else t
-        else:  # PIL image or HWC uint8 array -> what VaeImageProcessor.preprocess(do_normalize=False) yields
-            arr = np.asarray(image.convert("RGB") if hasattr(image, "convert") else image)
-            t = torch.from_numpy(arr).float().div(255.0).permute(2, 0, 1)[None]
+        else:  # PIL image or HWC uint8 array -> what VaeImageProcessor.preprocess(do_normalize=False) yields:
+            # RGB, Lanczos resize to the requested size, [0,1] floats (EDC:173-175, 1017)
+            if hasattr(image, "convert"):
+                image = image.convert("RGB")
+                if image.size != (w_px, h_px):
+                    from PIL import Image
+                    image = image.resize((w_px, h_px), resample=Image.LANCZOS)
+            arr = np.asarray(image)
+            t = torch.from_numpy(np.ascontiguousarray(arr)).float().div(255.0).permute(2, 0, 1)[None]
         if tuple(t.shape[-2:]) != (h_px, w_px):
             t = torch.nn.functional.interpolate(t, size=(h_px, w_px), mode="bilinear", align_corners=False)
         return t
