@@ -83,9 +83,9 @@ def gather_views(latent, out, win_y0, win_x0, Sh, Sw, off_y=0, off_x=0, frame=No
     if frame is not None:
         assert tuple(frame.shape) == (C, PH, PW)
     _call("ed_gather_views", _dev(latent, torch.float32, "latent"), _dev(out, None, "out"), _code(out, "out"),
-                                     B, C, H, W, _dev(win_y0, torch.int32, "win_y0"), _dev(win_x0, torch.int32, "win_x0"),
-                                     V, Sh, Sw, PH, PW, off_y, off_x, _opt(frame, torch.float32, "frame"),
-                                     float(divisor), _stream())
+          B, C, H, W, _dev(win_y0, torch.int32, "win_y0"), _dev(win_x0, torch.int32, "win_x0"),
+          V, Sh, Sw, PH, PW, off_y, off_x, _opt(frame, torch.float32, "frame"),
+          float(divisor), _stream())
     return out
 
 
@@ -96,9 +96,9 @@ def scatter_centres(pred, local, n_col_blocks, row_blk, row_src, col_blk, col_sr
     assert C2 == C and rows % B == 0
     assert row_blk.numel() == H * 2 == row_src.numel() and col_blk.numel() == W * 2 == col_src.numel()
     _call("ed_scatter_centres", _dev(pred, None, "pred"), _code(pred, "pred"), _dev(local, torch.float32, "local"),
-                                        B, C, H, W, PH, PW, n_col_blocks,
-                                        _dev(row_blk, torch.int32), _dev(row_src, torch.int32),
-                                        _dev(col_blk, torch.int32), _dev(col_src, torch.int32), _stream())
+          B, C, H, W, PH, PW, n_col_blocks,
+          _dev(row_blk, torch.int32), _dev(row_src, torch.int32),
+          _dev(col_blk, torch.int32), _dev(col_src, torch.int32), _stream())
     return local
 
 
@@ -115,10 +115,10 @@ def pick_assemble(latent, idx, src_row, src_col, out, h, w, off_y=0, off_x=0, fr
     if low is not None:
         assert tuple(low.shape) == (K, B, C, h, w)
     _call("ed_pick_assemble", _dev(latent, torch.float32, "latent"), _dev(idx, torch.uint8, "idx"),
-                                      _dev(src_row, torch.int32), _dev(src_col, torch.int32),
-                                      _opt(frame, torch.float32, "frame"), _dev(out, None, "out"), _code(out, "out"),
-                                      _opt(low, torch.float32, "low"), K, B, C, H, W, h, w, PH, PW, off_y, off_x,
-                                      _stream())
+          _dev(src_row, torch.int32), _dev(src_col, torch.int32),
+          _opt(frame, torch.float32, "frame"), _dev(out, None, "out"), _code(out, "out"),
+          _opt(low, torch.float32, "low"), K, B, C, H, W, h, w, PH, PW, off_y, off_x,
+          _stream())
     return out
 
 
@@ -130,8 +130,8 @@ def unpad_direction(unet_out, dirs, uncond_last, off_y=0, off_x=0):
     if uncond_last is not None:
         assert tuple(uncond_last.shape) == (B, C, h, w)
     _call("ed_unpad_direction", _dev(unet_out, None, "unet_out"), _code(unet_out, "unet_out"),
-                                        _dev(dirs, torch.float32, "dirs"), _opt(uncond_last, torch.float32, "uncond_last"),
-                                        K, B, C, h, w, PH, PW, off_y, off_x, _stream())
+          _dev(dirs, torch.float32, "dirs"), _opt(uncond_last, torch.float32, "uncond_last"),
+          K, B, C, h, w, PH, PW, off_y, off_x, _stream())
     return dirs
 
 
@@ -143,11 +143,11 @@ def fill_directions(dirs, stamp, inv_row, inv_col, up_row, up_col, down_row, dow
     assert inv_row.numel() == 2 * H and inv_col.numel() == 2 * W and up_row.numel() == H and up_col.numel() == W
     assert down_row.numel() == h and down_col.numel() == w
     _call("ed_fill_directions", _dev(dirs, torch.float32, "dirs"), _dev(stamp, torch.int8, "stamp"),
-                                        _dev(inv_row, torch.int32), _dev(inv_col, torch.int32),
-                                        _dev(up_row, torch.int32), _dev(up_col, torch.int32),
-                                        _dev(down_row, torch.int32), _dev(down_col, torch.int32),
-                                        _dev(target, torch.float32, "target"), _opt(low_dir, torch.float32, "low_dir"),
-                                        K, B, C, H, W, h, w, _stream())
+          _dev(inv_row, torch.int32), _dev(inv_col, torch.int32),
+          _dev(up_row, torch.int32), _dev(up_col, torch.int32),
+          _dev(down_row, torch.int32), _dev(down_col, torch.int32),
+          _dev(target, torch.float32, "target"), _opt(low_dir, torch.float32, "low_dir"),
+          K, B, C, H, W, h, w, _stream())
     return target
 
 
@@ -156,8 +156,8 @@ def cfg_ddim_step(local, direction, x, prev, x0, g, sqrt_beta_t, sqrt_alpha_t, s
     for t in (local, direction, prev, x0):
         assert t.numel() == n
     _call("ed_cfg_ddim_step", _dev(local, torch.float32), _dev(direction, torch.float32), _dev(x, torch.float32),
-                                      _dev(prev, torch.float32), _dev(x0, torch.float32), float(g), float(sqrt_beta_t),
-                                      float(sqrt_alpha_t), float(sqrt_alpha_prev), float(sqrt_1m_alpha_prev), n, _stream())
+          _dev(prev, torch.float32), _dev(x0, torch.float32), float(g), float(sqrt_beta_t),
+          float(sqrt_alpha_t), float(sqrt_alpha_prev), float(sqrt_1m_alpha_prev), n, _stream())
     return prev, x0
 
 
@@ -167,7 +167,7 @@ def undo_step(x_in, noise, coef, x_out):
     n_sub = noise.shape[0]
     assert noise.numel() == n_sub * n and coef.numel() == 2 * n_sub and x_out.numel() == n
     _call("ed_undo_step", _dev(x_in, torch.float32), _dev(noise, torch.float32), _dev(coef, torch.float32),
-                                  _dev(x_out, torch.float32), n_sub, n, _stream())
+          _dev(x_out, torch.float32), n_sub, n, _stream())
     return x_out
 
 
@@ -177,10 +177,10 @@ def rrg_update(prev, x0, low_latent, low_uncond, low_dir, up_row, up_col, out, g
     assert tuple(low_latent.shape) == (B, C, h, w) == tuple(low_uncond.shape) == tuple(low_dir.shape)
     assert up_row.numel() == H and up_col.numel() == W
     _call("ed_rrg_update", _dev(prev, torch.float32), _dev(x0, torch.float32), _dev(low_latent, torch.float32),
-                                   _dev(low_uncond, torch.float32), _dev(low_dir, torch.float32),
-                                   _dev(up_row, torch.int32), _dev(up_col, torch.int32), _dev(out, torch.float32),
-                                   float(g), float(sqrt_beta_t), float(sqrt_alpha_t), float(norm), float(weight),
-                                   B, C, H, W, h, w, _stream())
+          _dev(low_uncond, torch.float32), _dev(low_dir, torch.float32),
+          _dev(up_row, torch.int32), _dev(up_col, torch.int32), _dev(out, torch.float32),
+          float(g), float(sqrt_beta_t), float(sqrt_alpha_t), float(norm), float(weight),
+          B, C, H, W, h, w, _stream())
     return out
 
 
@@ -190,8 +190,8 @@ def gather2d(inp, out, src_n, rows, cols):
     N, C2, oh, ow = out.shape
     assert C2 == C and tuple(rows.shape) == (N, oh) and tuple(cols.shape) == (N, ow) and src_n.numel() == N
     _call("ed_gather2d", _dev(inp, None, "inp"), _code(inp, "inp"), _dev(out, None, "out"), _code(out, "out"),
-                                 C, H, W, _dev(src_n, torch.int32), _dev(rows, torch.int32), _dev(cols, torch.int32),
-                                 N, oh, ow, _stream())
+          C, H, W, _dev(src_n, torch.int32), _dev(rows, torch.int32), _dev(cols, torch.int32),
+          N, oh, ow, _stream())
     return out
 
 
@@ -202,8 +202,8 @@ def tile_gather_pad(latent, tiles, tile_y0, tile_x0, scaling_factor):
     rows, C2, Ts, Ts2 = tiles.shape
     assert rows == T * B and C2 == C and Ts == Ts2
     _call("ed_tile_gather_pad", _dev(latent, torch.float32), _dev(tiles, None, "tiles"), _code(tiles, "tiles"),
-                                        B, C, H, W, _dev(tile_y0, torch.int32), _dev(tile_x0, torch.int32), T, Ts,
-                                        float(scaling_factor), _stream())
+          B, C, H, W, _dev(tile_y0, torch.int32), _dev(tile_x0, torch.int32), T, Ts,
+          float(scaling_factor), _stream())
     return tiles
 
 
@@ -217,9 +217,9 @@ def tile_accumulate_normalise(decoded, image, n_col_tiles, row_tile, row_src, co
     assert C2 == Cimg and TP == TP2 and rows % B == 0
     assert row_tile.numel() == HP * TILE_MAXC == row_src.numel() and col_tile.numel() == WP * TILE_MAXC == col_src.numel()
     _call("ed_tile_accumulate_normalise", _dev(decoded, None, "decoded"), _code(decoded, "decoded"),
-                                                  _dev(image, torch.float32), B, Cimg, HP, WP, TP, n_col_tiles,
-                                                  _dev(row_tile, torch.int32), _dev(row_src, torch.int32),
-                                                  _dev(col_tile, torch.int32), _dev(col_src, torch.int32), _stream())
+          _dev(image, torch.float32), B, Cimg, HP, WP, TP, n_col_tiles,
+          _dev(row_tile, torch.int32), _dev(row_src, torch.int32),
+          _dev(col_tile, torch.int32), _dev(col_src, torch.int32), _stream())
     return image
 
 

@@ -34,6 +34,10 @@ def _identity_progress(it):
     return it
 
 
+class _Plan:
+    """Per-call geometry: host plans (geometry.py) + their int32 device tables + the pick sampler."""
+
+
 class _Stager:
     """Pinned host staging ring: host RNG results are written into pinned memory and uploaded with an async copy;
     a slot is reused only after its copy event has completed, so the host may run ahead of the GPU."""
@@ -119,7 +123,6 @@ class ElasticDiffusion(nn.Module):
         self.default_size = None
         self._stager = _Stager()
         self.last_latents = None
-        self.stats = {}
 
     def _mark(self, name):
         """Phase markers (HIP events on the current stream; read only by ``phase_times`` after a sync)."""
@@ -188,7 +191,7 @@ class ElasticDiffusion(nn.Module):
         Hl, Wl = height // s, width // s
         h, w = self.get_downsample_size(height, width)
         vc = self.view_config
-        P = type("Plan", (), {})()
+        P = _Plan()
         P.Hl, P.Wl, P.h, P.w = Hl, Wl, h, w
         P.pick = geometry.PickPlan(Hl, Wl, h, w)
         P.views = geometry.ViewPlan(Hl, Wl, vc["window_size"], vc["stride"], vc["context_size"])

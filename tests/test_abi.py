@@ -25,6 +25,24 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in the header but not exported"
         n_args = 0 if args.strip() in ("", "void") else len([a for a in args.split(",") if a.strip()])
         assert n_args == len(_hip.SIGNATURES[name]), f"{name}: header has {n_args} args, ctypes table {len(_hip.SIGNATURES[name])}"
+    # argument types, position by position
+    import ctypes
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_int64: "int64"}
+    for name, args in declared:
+        want = []
+        for a in [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]:
+            if "*" in a:
+                want.append("ptr")
+            elif re.match(r"(const\s+)?int64_t\b", a):
+                want.append("int64")
+            elif re.match(r"(const\s+)?float\b", a):
+                want.append("float")
+            elif re.match(r"(const\s+)?int\b", a):
+                want.append("int")
+            else:
+                raise AssertionError(f"{name}: unparsed argument {a!r}")
+        got = [kinds[t] for t in _hip.SIGNATURES[name]]
+        assert got == want, f"{name}: ctypes {got} != header {want}"
     assert L.ed_version() == _hip.ABI_VERSION
     assert L.ed_error_string(0)
 
