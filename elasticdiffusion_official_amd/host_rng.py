@@ -17,6 +17,9 @@ import numpy as np
 import torch
 
 
+MAX_RESAMPLING_STEPS = 126  # K = R+1 steps are stamped into an int8 table (values -1 .. K-1 <= 126)
+
+
 def seed_everything(seed, seed_np=True):
     """ED:165-171 (the reference also seeds the CUDA generator; device-side generators are never used here)."""
     torch.manual_seed(seed)

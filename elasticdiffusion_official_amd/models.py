@@ -588,14 +588,15 @@ def family(sd_version):
 
 
 def _seeded_init(module, seed):
-    """Deterministic synthetic weights (no checkpoints exist offline): PyTorch default init under a private seed,
-    final output convs scaled down so a 50-step loop stays well inside fp32/bf16 range."""
-    dev_state = torch.random.get_rng_state()
-    torch.manual_seed(seed)
-    for m in module.modules():
-        if hasattr(m, "reset_parameters"):
-            m.reset_parameters()
-    torch.random.set_rng_state(dev_state)
+    """Deterministic synthetic weights (no checkpoints exist offline): PyTorch's default ``reset_parameters`` init under
+    a private seed (measured: the random-init SDXL loop stays finite over 50 steps in bf16 without any rescaling).
+    ``torch.random.fork_rng`` restores the CPU generator and the generator of the device being initialised."""
+    devs = sorted({p.device.index for p in module.parameters() if p.is_cuda and p.device.index is not None})
+    with torch.random.fork_rng(devices=devs):
+        torch.manual_seed(seed)
+        for m in module.modules():
+            if hasattr(m, "reset_parameters"):
+                m.reset_parameters()
 
 
 def load_weights(module, path):

@@ -9,8 +9,18 @@ ED_F32, ED_F16, ED_BF16 = 0, 1, 2
 _DTYPE = {torch.float32: ED_F32, torch.float16: ED_F16, torch.bfloat16: ED_BF16}
 
 
+# Device of the launch being assembled: every ``_dev`` of one wrapper call must name the same ROCm device; ``_stream``
+# (always the last argument evaluated) and ``_call`` then use THAT device's current stream and make it the current
+# device around the ctypes launch.  Nothing here depends on the process-wide current device (ADVICE r1:
+# ``ElasticDiffusion('cuda:1')`` in a process whose current device is 0 must not launch on device 0).
+_LAUNCH = {"device": None}
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    dev = _LAUNCH["device"]
+    if dev is None:
+        raise RuntimeError("internal: _stream() before any device tensor argument")
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 class KernelTimer:
@@ -40,6 +50,11 @@ TIMER = KernelTimer()
 
 def _call(name, *args):
     fn = getattr(_hip.lib(), name)
+    dev, _LAUNCH["device"] = _LAUNCH["device"], None
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):  # a HIP launch runs on the calling thread's current device
+            _LAUNCH["device"] = dev
+            return _call(name, *args)
     if TIMER.enabled and not torch.cuda.is_current_stream_capturing():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -51,14 +66,23 @@ def _call(name, *args):
     _hip.check(err, name)
 
 
+def _reject(msg):
+    _LAUNCH["device"] = None  # an abandoned launch must not leak its device into the next one
+    raise RuntimeError(msg)
+
+
 def _dev(t, dtype=None, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise RuntimeError(f"{name} must be a tensor on the MI355X (got {type(t).__name__}"
-                           f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); no CPU fallback")
+        _reject(f"{name} must be a tensor on the MI355X (got {type(t).__name__}"
+                f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); no CPU fallback")
     if not t.is_contiguous():
-        raise RuntimeError(f"{name} must be contiguous")
+        _reject(f"{name} must be contiguous")
     if dtype is not None and t.dtype != dtype:
-        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+        _reject(f"{name} must be {dtype}, got {t.dtype}")
+    if _LAUNCH["device"] is None:
+        _LAUNCH["device"] = t.device
+    elif _LAUNCH["device"] != t.device:
+        _reject(f"{name} lives on {t.device} but an earlier argument of this launch is on {_LAUNCH['device']}")
     return t.data_ptr()
 
 
@@ -70,7 +94,7 @@ def _code(t, name):
     try:
         return _DTYPE[t.dtype]
     except KeyError:
-        raise RuntimeError(f"{name}: unsupported dtype {t.dtype}") from None
+        _reject(f"{name}: unsupported dtype {t.dtype}")
 
 
 def gather_views(latent, out, win_y0, win_x0, Sh, Sw, off_y=0, off_x=0, frame=None, divisor=1.0):

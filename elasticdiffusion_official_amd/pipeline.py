@@ -34,6 +34,39 @@ def _identity_progress(it):
     return it
 
 
+def _make_grid(imgs, nrow=8, padding=2):
+    """torchvision.utils.make_grid for a (N,C,H,W) batch with its defaults (what ED:1124 calls): a single image is
+    returned as is; otherwise ``min(nrow, N)`` images per row, each cell offset by ``padding`` px of zeros (one shared
+    2-px line between neighbours, a 2-px border top/left and bottom/right)."""
+    N, C, H, W = imgs.shape
+    if N == 1:
+        return imgs[0]
+    xmaps = min(nrow, N)
+    ymaps = -(-N // xmaps)
+    h, w = H + padding, W + padding
+    grid = imgs.new_zeros(C, h * ymaps + padding, w * xmaps + padding)
+    for k in range(N):
+        y, x = divmod(k, xmaps)
+        grid[:, y * h + padding:y * h + padding + H, x * w + padding:x * w + padding + W] = imgs[k]
+    return grid
+
+
+def _on_own_device(fn):
+    """Run a pipeline entry point with the pipeline's device current: hipGraph capture, side streams, events and the
+    torch ops of the model all follow the calling thread's current device, and the reference accepts any device
+    (``ElasticDiffusion(torch.device('cuda:1'))`` in a process whose current device is 0)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        if self.device.index is None or self.device.index == torch.cuda.current_device():
+            return fn(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+
+    return wrapper
+
+
 class _Plan:
     """Per-call geometry: host plans (geometry.py) + their int32 device tables + the pick sampler."""
 
@@ -68,8 +101,9 @@ class _Stager:
     def upload(self, host_buf, device):
         dev = torch.empty(host_buf.shape, dtype=host_buf.dtype, device=device)
         dev.copy_(host_buf, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        with torch.cuda.device(device):  # the copy ran on ``device``'s current stream: record the event there
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
         self.slot_of[host_buf.data_ptr()][1] = ev
         return dev
 
@@ -84,6 +118,8 @@ class ElasticDiffusion(nn.Module):
                  model_dtype=None, weights=None, cache_backgrounds=False, use_graphs=True):
         super().__init__()
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())
         if device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("elasticdiffusion_official_amd runs the hot path in HIP kernels on an MI355X; "
                                f"device={device} is not a ROCm device and there is no CPU fallback "
@@ -106,7 +142,14 @@ class ElasticDiffusion(nn.Module):
         self.unet = unet.to(device)
         self.vae = vae.to(device)
         self.controlnet = controlnet.to(device) if controlnet is not None else None
-        self.scheduler = scheduler if scheduler is not None else DDIMSchedule()
+        if scheduler is None:
+            scheduler = DDIMSchedule.from_config_dir(weights) if weights else DDIMSchedule()  # ED:153
+        self.scheduler = scheduler
+        if text_encoder is None and weights:
+            # real UNet/VAE weights with synthetic prompt embeddings would be prompt-independent garbage: a snapshot
+            # must carry its CLIP encoders (ED:145-151); a failure to load them is an error, not a silent fallback
+            from .text import load_clip
+            text_encoder = load_clip(weights, xl, device)
         self.text_encoder = text_encoder
         self.model_size = 128 if xl else 64  # d_H, d_W of ED:398-400
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)  # ED:156
@@ -128,13 +171,14 @@ class ElasticDiffusion(nn.Module):
         """Phase markers (HIP events on the current stream; read only by ``phase_times`` after a sync)."""
         if name == "start":
             self._marks = []
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
+        with torch.cuda.device(self.device):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
         self._marks.append((name, ev))
 
     def phase_times(self):
         """-> {phase: ms} of the last generate_image call (synchronises)."""
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         m = self._marks
         return {b[0]: a[1].elapsed_time(b[1]) for a, b in zip(m[:-1], m[1:])}
 
@@ -389,6 +433,7 @@ class ElasticDiffusion(nn.Module):
         return out
 
     # ---- the loop (ED:953-1078) --------------------------------------------------------------------
+    @_on_own_device
     @torch.no_grad()
     def generate_latents(self, prompts, negative_prompts="", height=768, width=768, num_inference_steps=50,
                          guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
@@ -422,7 +467,10 @@ class ElasticDiffusion(nn.Module):
         self._timesteps = list(ts)
         self._t_dev = ts.to(dev)
         self._step_coef = [self.scheduler.step_coefficients(t) for t in ts]
-        R = resampling_steps
+        R = int(resampling_steps)
+        if not 0 <= R <= host_rng.MAX_RESAMPLING_STEPS:
+            raise ValueError(f"resampling_steps must be in [0, {host_rng.MAX_RESAMPLING_STEPS}] (the per-pixel "
+                             f"last-covering-step table is int8), got {resampling_steps}")
         repaint = bool(repaint_sampling) and R > 0
         if repaint:
             # undo_step is only ever entered with timesteps[i+1] (ED:1040): row 0 is a placeholder
@@ -469,12 +517,14 @@ class ElasticDiffusion(nn.Module):
         return x
 
     # ---- decode (ED:267-310) -----------------------------------------------------------------------
+    @_on_own_device
     @torch.no_grad()
     def decode_latents(self, latents):
         vdt = next(self.vae.parameters()).dtype
         img = self.vae.decode((latents / self.vae.config.scaling_factor).to(vdt)).sample
         return (img.float() / 2 + 0.5).clamp(0, 1)
 
+    @_on_own_device
     @torch.no_grad()
     def tiled_decode(self, latents, tile_batch=8):
         """ED:275-310 with the tiles gathered in one launch, decoded ``tile_batch`` at a time (and sharded over ranks),
@@ -498,6 +548,7 @@ class ElasticDiffusion(nn.Module):
                                       self._dev_i32(ct), self._dev_i32(cs))
         return image
 
+    @_on_own_device
     @torch.no_grad()
     def generate_image(self, prompts, negative_prompts="", height=768, width=768, num_inference_steps=50,
                        guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
@@ -514,7 +565,7 @@ class ElasticDiffusion(nn.Module):
         imgs = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])  # decode_bs = 1 (ED:1090, 1121)
         self._mark("decode_done")
         if grid:
-            imgs = torch.cat(list(imgs), dim=-1)[None]  # make_grid(nrows=len) without padding lines
+            imgs = _make_grid(imgs)[None]  # ED:1124: torchvision make_grid(imgs, nrow=8, padding=2, pad_value=0)
         if output_type == "pt":
             return imgs, {}
         from PIL import Image

@@ -37,6 +37,21 @@ class DDIMSchedule:
         self.num_inference_steps = None
         self.timesteps = None
 
+    @classmethod
+    def from_config_dir(cls, model_dir):
+        """``DDIMScheduler.from_pretrained(model_key, subfolder="scheduler")`` (ED:153) for a local HF snapshot: reads
+        ``<model_dir>/scheduler/scheduler_config.json`` when present (keys this class does not know are ignored, values
+        it cannot honour -- v-prediction, trailing spacing -- raise NotImplementedError), defaults otherwise."""
+        import json
+        import os
+        path = os.path.join(model_dir, "scheduler", "scheduler_config.json")
+        if not os.path.isfile(path):
+            return cls()
+        cfg = json.load(open(path))
+        known = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "set_alpha_to_one", "steps_offset",
+                 "prediction_type", "timestep_spacing", "clip_sample")
+        return cls(**{k: cfg[k] for k in known if k in cfg})
+
     def set_timesteps(self, num_inference_steps):
         n = self.config.num_train_timesteps
         if num_inference_steps > n:

@@ -65,7 +65,12 @@ def test_groupnorm(dtype, N, C, H, W, silu, tokens):
     rel = float((got.float() - ref).norm() / ref.norm())
     rel_torch = float((want.float() - ref).norm() / ref.norm())
     assert rel < 1.5 * rel_torch + 1e-6, (rel, rel_torch)  # as accurate as the torch kernel it replaces
-    assert float((got == want).float().mean()) > 0.5        # and mostly bit-identical to it
+    # and bit-identical to torch's 16-bit kernel wherever the group statistics agree to the last fp32 bit; they are
+    # accumulated in a different order (sum/sumsq + Chan merge vs Welford), which flips the 16-bit rounding of a
+    # fraction of the elements (more of them in fp16, whose ulp is 8x finer than bf16's)
+    same = float((got == want).float().mean())
+    print(f"groupnorm {dtype} {N}x{C}x{H}x{W} silu={silu} tokens={tokens}: bit-identical to torch {same:.4f}")
+    assert same > (0.9 if dtype == torch.bfloat16 else 0.7), same
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -155,11 +160,14 @@ def test_unet_fused_vs_unfused_close():
     e = torch.randn(3, 77, 64, device=DEV, dtype=torch.bfloat16)
     kw = {"text_embeds": torch.randn(3, 16, device=DEV, dtype=torch.bfloat16), "time_ids": torch.zeros(3, 6, device=DEV)}
     t = torch.tensor(500, device=DEV)
-    with torch.no_grad():
-        M.FUSED_KERNELS = True
-        a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
-        M.FUSED_KERNELS = M.SHORTCUT_AS_GEMM = False
-        b = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
-        M.FUSED_KERNELS = M.SHORTCUT_AS_GEMM = True
+    saved = (M.FUSED_KERNELS, M.SHORTCUT_AS_GEMM)
+    try:
+        with torch.no_grad():
+            M.FUSED_KERNELS = M.SHORTCUT_AS_GEMM = True
+            a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+            M.FUSED_KERNELS = M.SHORTCUT_AS_GEMM = False
+            b = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+    finally:
+        M.FUSED_KERNELS, M.SHORTCUT_AS_GEMM = saved  # module switches must not leak into later tests
     rel = float((a - b).norm() / b.norm())
     assert a.is_contiguous() and rel < 2e-2, rel
