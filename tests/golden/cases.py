@@ -42,7 +42,25 @@ G7_CASES = {
     "tiles_exact": (16, 24, 32, False, 0),
     "tiles_ragged": (20, 28, 32, False, 1),
     "tiles_lowvram": (20, 28, 32, True, 2),
+    # cfg4 size: 64 tiles of 128x128 latents (32-latent cores + 48-latent halo), 2048x2048 px image -> stored as probes
+    "tiles_cfg4_256": (256, 256, 128, False, 3),
 }
+
+# images larger than this many elements are stored as ``image_probe`` vectors instead of in full
+FULL_IMAGE_MAX = 1 << 20
+
+
+def image_probe(img):
+    """Compact fingerprint of a large decoded image (B,3,H,W): 16x16 block means, a strided sample, and the full
+    rows / columns either side of the first few tile seams (core = 256 px) -- seams are where a tiled-decode bug shows.
+    Same function on the writer (reference output) and the reader (HIP output) side."""
+    import torch.nn.functional as F
+    img = img.detach().float().cpu()
+    H, W = img.shape[-2:]
+    seams_r = [r for r in (255, 256, 511, 512, H - 257, H - 256) if 0 <= r < H]
+    seams_c = [c for c in (255, 256, 767, 768, W - 257, W - 256) if 0 <= c < W]
+    return {"pool16": F.avg_pool2d(img, 16), "stride": img[..., 5::16, 11::16].contiguous(),
+            "seam_rows": img[..., seams_r, :].contiguous(), "seam_cols": img[..., :, seams_c].contiguous()}
 
 E2E_KW = dict(guidance_scale=10.0, new_p=0.3, rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0,
               repaint_sampling=True)
@@ -64,6 +82,11 @@ E2E_CASES = {
     "cn_sd_512x1024": dict(sd="1.5", sample=64, vbs=4, H=512, W=1024, steps=3, R=2, seed=7, controlnet=True),
     "cfg5_cn_xl_1024x2048": dict(sd="XL1.0", sample=128, vbs=16, H=1024, W=2048, steps=2, R=1, seed=8,
                                  controlnet=True),
+    # BASELINE.json configs[3]: SDXL 2048x2048, 16 views, tiled decode (64 tiles); image stored as probes
+    "cfg4_xl_2048x2048_tiled": dict(sd="XL1.0", sample=128, vbs=16, H=2048, W=2048, steps=2, R=2, seed=9, tiled=True,
+                                    keep_image=True, kw=dict(rrg_init_weight=4000)),
+    # non-tiled decode image compared too (only latents were)
+    "cfg2_image_sd_512x1024": dict(sd="1.5", sample=64, vbs=4, H=512, W=1024, steps=2, R=1, seed=10, keep_image=True),
 }
 
 
@@ -75,3 +98,17 @@ def synthetic_condition(h_px, w_px):
     g = xs.expand(1, 1, h_px, w_px)
     b = (0.5 + 0.5 * torch.sin(6.0 * (ys + xs))).expand(1, 1, h_px, w_px)
     return torch.cat([r, g, b], dim=1).contiguous()
+
+
+def assert_image_matches(g, name, img, atol):
+    """Compare a decoded image with the stored golden: in full when ``<name>/image`` exists, through
+    ``image_probe`` vectors otherwise."""
+    import numpy as np
+    img = img.detach().float().cpu()
+    if f"{name}/image" in g.files:
+        np.testing.assert_allclose(img.numpy(), g[f"{name}/image"], rtol=0, atol=atol)
+        return
+    probes = image_probe(img)
+    assert f"{name}/image_probe/pool16" in g.files, f"no golden image for {name}"
+    for k, v in probes.items():
+        np.testing.assert_allclose(v.numpy(), g[f"{name}/image_probe/{k}"], rtol=0, atol=atol, err_msg=k)

@@ -57,6 +57,15 @@ def save(name, **arrays):
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def store_image(out, name, img):
+    """Full image for small cases, ``cases.image_probe`` vectors for cfg4-sized ones (48 MiB fp32 otherwise)."""
+    if img.numel() <= cases.FULL_IMAGE_MAX:
+        out[f"{name}/image"] = img
+    else:
+        for k, v in cases.image_probe(img).items():
+            out[f"{name}/image_probe/{k}"] = v
+
+
 # ---------------------------------------------------------------------------------------------------
 def g1_views():
     pipe, _, _ = build()
@@ -153,7 +162,7 @@ def g7_tiled_decode():
         pipe, _, _ = build(sample_size=sample)
         pipe.low_vram = low_vram  # geometry switch only (ED:283-285); latents stay fp32
         z = torch.randn(1, 4, Hl, Wl, generator=torch.Generator().manual_seed(seed))
-        out[f"{name}/image"] = pipe.tiled_decode(z)
+        store_image(out, name, pipe.tiled_decode(z))
     save("g7_tiled_decode", **out)
 
 
@@ -224,7 +233,7 @@ def g8_g10_end_to_end():
                                 rrg_scherduler_cls=ref.CosineScheduler, tiled_decoder=bool(c.get("tiled")), **kw)
         out[f"{name}/latent"] = cap["z"]
         if c.get("keep_image"):
-            out[f"{name}/image"] = cap["img"]
+            store_image(out, name, cap["img"])
         out[f"{name}/rng_tail"] = torch.rand(4)
         if c.get("trace"):
             traces[name] = tr.events

@@ -221,7 +221,7 @@ def test_tiled_decode_vs_golden_and_oracle(golden_dir, name):
     pipe = ElasticDiffusion(DEV, "1.5", unet=FakeUNet(sample), vae=FakeVAE(), low_vram=low_vram)
     z = torch.randn(1, 4, Hl, Wl, generator=torch.Generator().manual_seed(seed))
     img = pipe.tiled_decode(z.to(DEV), tile_batch=3).cpu()
-    np.testing.assert_allclose(img.numpy(), g[f"{name}/image"], rtol=0, atol=2e-5)
+    cases.assert_image_matches(g, name, img, 2e-5)
 
 
 def test_gather2d_nearest_and_zero_pad():
@@ -309,7 +309,7 @@ def test_end_to_end_vs_oracle_and_golden(golden_dir, name):
     assert z.shape == want.shape
     assert rel_l2(z, want) < 1e-4, rel_l2(z, want)
     if c.get("keep_image"):
-        assert (imgs.cpu() - torch.from_numpy(g[f"{name}/image"])).abs().max() < 1e-3
+        cases.assert_image_matches(g, name, imgs, 1e-3)
     # the host generators end in exactly the reference's state
     np.testing.assert_array_equal(tail.numpy(), g[f"{name}/rng_tail"])
     assert log == {}

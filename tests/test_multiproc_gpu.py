@@ -62,7 +62,7 @@ def _worker(rank, world, port, name, ret):
 
 
 @pytest.mark.parametrize("world,name", [(2, "cfg2_sd_512x1024"), (3, "cfg3_xl_1024x2048"), (2, "tiled_sd_640x512"),
-                                        (2, "cn_sd_512x1024")])
+                                        (2, "cn_sd_512x1024"), (3, "cfg4_xl_2048x2048_tiled")])
 def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
     g = np.load(os.path.join(golden_dir, "g8_end_to_end.npz"))
     ctx = mp.get_context("spawn")

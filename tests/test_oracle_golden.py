@@ -141,7 +141,7 @@ def test_g7_tiled_decode(golden_dir, name):
     orc, _ = make_oracle(sample=sample)
     orc.low_vram = low_vram
     z = torch.randn(1, 4, Hl, Wl, generator=torch.Generator().manual_seed(seed))
-    close(orc.tiled_decode(z), g[f"{name}/image"])
+    cases.assert_image_matches(g, name, orc.tiled_decode(z), ATOL)
 
 
 @pytest.mark.parametrize("name", list(cases.E2E_CASES))
@@ -162,7 +162,7 @@ def test_g8_g10_end_to_end(golden_dir, name):
     rel = np.linalg.norm(z.numpy() - want) / np.linalg.norm(want)
     assert rel < 1e-5, rel
     if c.get("keep_image"):
-        close(img, g[f"{name}/image"], 1e-4)
+        cases.assert_image_matches(g, name, img, 1e-4)
     np.testing.assert_array_equal(torch.rand(4).numpy(), g[f"{name}/rng_tail"])
 
 

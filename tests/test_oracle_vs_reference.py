@@ -21,6 +21,7 @@ CASES = [
     ("XL1.0", 1024, 1536, 2, 1, 2, 18, 96, False, False),
     ("1.5", 512, 1024, 2, 2, 4, 19, None, False, True),
     ("XL1.0", 1024, 2048, 2, 1, 16, 20, None, False, True),
+    ("XL1.0", 2048, 2048, 2, 2, 16, 21, None, True, False),   # cfg4: 16 views, 64-tile decode
 ]
 
 
