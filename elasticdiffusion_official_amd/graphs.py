@@ -25,12 +25,20 @@ class GraphedForward:
         self.warmup_iters = warmup_iters
         self.entries = {}
         self.epoch = 0
+        self.replays = 0
 
     def fwd(self, *a):
         f = self._fwd_ref()
         if f is None:
             raise RuntimeError("the pipeline that owns this GraphedForward is gone")
         return f(*a)
+
+    def stats(self):
+        """{"captured": shapes replayed as hipGraphs, "eager": shapes whose capture failed (run eagerly), "replays": n}
+        -- reported in bench.py's JSON so a silent fallback to eager launches cannot hide a regression."""
+        ents = list(self.entries.values())
+        return {"enabled": bool(self.enabled), "captured": sum(e["graph"] is not None for e in ents),
+                "eager": sum(bool(e["eager"]) for e in ents), "replays": self.replays}
 
     def new_image(self):
         """Side inputs (text / pooled / condition rows) may have changed: re-copy them on next use."""
@@ -109,4 +117,5 @@ class GraphedForward:
                     ent[name].copy_(src)
             ent["epoch"] = self.epoch
         ent["graph"].replay()
+        self.replays += 1
         return ent["out"]

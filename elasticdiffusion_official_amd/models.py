@@ -252,6 +252,22 @@ UNET_CONFIGS = {
 }
 
 
+# Reduced-width variants of the same architectures (same block structure, attention placement, projection kind, head
+# dim 64, added-condition path): small enough that the fp32 CPU oracle runs them in seconds, so the parity tests and
+# bench.py's parity leg can put the REAL module code (not a stand-in) inside an oracle-checked denoising loop.
+SMALL_UNET_CONFIGS = {
+    "sd15": dict(sample_size=64, in_channels=4, block_out_channels=(64, 128, 256, 256), layers_per_block=2,
+                 attn=(True, True, True, False), transformer_depth=(1, 1, 1, 1), heads=(1, 2, 4, 4),
+                 cross_attention_dim=64, use_linear_projection=False, addition_time_embed_dim=None,
+                 pooled_projection_dim=None),
+    "sdxl": dict(sample_size=128, in_channels=4, block_out_channels=(64, 128, 256), layers_per_block=2,
+                 attn=(False, True, True), transformer_depth=(1, 1, 2), heads=(1, 2, 4),
+                 cross_attention_dim=64, use_linear_projection=True, addition_time_embed_dim=16,
+                 pooled_projection_dim=32),
+}
+SMALL_VAE_CHANNELS = (32, 64, 64, 64)
+
+
 class _DownBlock(nn.Module):
     def __init__(self, cin, cout, temb, layers, attn, heads, depth, cross, linear, downsample):
         super().__init__()
@@ -609,16 +625,18 @@ def load_weights(module, path):
     return module
 
 
-def build_models(sd_version, device="cuda", dtype=None, weights=None, vae_dtype=torch.float32, controlnet=False, seed=0):
+def build_models(sd_version, device="cuda", dtype=None, weights=None, vae_dtype=torch.float32, controlnet=False, seed=0,
+                 small=False):
     """(unet, vae[, controlnet]) for the reference's ``sd_version`` keys (ED:128-141).  UNet/ControlNet run in bf16 by
     default; the VAE stays fp32 like the reference (its decode runs outside autocast, ED:1080-1121, and the encoder is
-    explicitly kept out of autocast, ED:328)."""
+    explicitly kept out of autocast, ED:328).  ``small=True`` builds the reduced-width variants (parity checks)."""
     fam = family(sd_version)
-    cfg = UNET_CONFIGS[fam]
+    cfg = (SMALL_UNET_CONFIGS if small else UNET_CONFIGS)[fam]
     dtype = dtype or torch.bfloat16
     with torch.device("meta"):
         unet = UNet2DConditionModel(**cfg)
-        vae = AutoencoderKL(scaling_factor=0.13025 if fam == "sdxl" else 0.18215, force_upcast=(fam == "sdxl"))
+        vae_kw = dict(block_out_channels=SMALL_VAE_CHANNELS) if small else {}
+        vae = AutoencoderKL(scaling_factor=0.13025 if fam == "sdxl" else 0.18215, force_upcast=(fam == "sdxl"), **vae_kw)
         cn = ControlNetModel(cfg) if controlnet else None
     out = []
     for k, (m, dt, sub) in enumerate([(unet, dtype, "unet"), (vae, vae_dtype, "vae"), (cn, dtype, "controlnet")]):

@@ -1,0 +1,147 @@
+"""Real-architecture parity harness (test infrastructure; also used by bench.py's parity leg).
+
+Round-1 parity ran a one-conv fp32 stand-in model (tests/fakes.py) through the loop: that proves the latent-space glue,
+not the model boundary.  Here the repo's OWN ``UNet2DConditionModel`` / ``AutoencoderKL`` / ``ControlNetModel`` classes
+(elasticdiffusion_official_amd/models.py, reduced width so the CPU side stays in seconds -- ``SMALL_UNET_CONFIGS``)
+run inside the product loop on the MI355X and, with the SAME weights in fp32 on the CPU, inside the oracle
+(oracle/elastic_oracle.py = the reference's loop, elastic_diffusion.py:1012-1078, pad strips :327-364).  That puts
+under parity: the fused UNet kernels (GroupNorm/SiLU, GEGLU, LayerNorm, flash attention, fused residual adds) in the
+16-bit runs, the hipGraph replay, the K = R+1 batched forward, ``_embed_rows``, and the real ``DiagonalGaussian``
+pad-strip path through a real VAE encoder.
+
+Three comparisons per geometry, each per timestep (relative L2 of the latent after every denoising step):
+  * ``fp32``      product with the fp32 model on the GPU            vs oracle with the fp32 model on the CPU  (GATE 1e-3)
+  * ``bf16``      product with the bf16 model on the GPU            vs the same fp32 oracle                   (reported)
+  * ``batching``  product bf16 (K resampling pairs + V views in ONE forward) vs the reference's call pattern
+                  (batch-2 calls per resampling step, ED:661-681; view batches of view_batch_size, ED:830-850) driving
+                  the SAME bf16 GPU model                                                                      (reported)
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from oracle.ddim import DDIMOracle
+from oracle.elastic_oracle import ElasticOracle
+from tests.fakes import synthetic_text_embeds
+from tests.golden import cases
+
+# name -> geometry + loop settings (BASELINE.json configs[1], [2], [4] geometries; 2 steps keep the oracle in seconds)
+REAL_CASES = {
+    "cfg2_sd_512x1024": dict(sd="1.5", H=512, W=1024, vbs=4, steps=3, R=2, seed=0),
+    "cfg3_xl_1024x2048": dict(sd="XL1.0", H=1024, W=2048, vbs=16, steps=2, R=2, seed=1),
+    "cfg5_cn_xl_1024x2048": dict(sd="XL1.0", H=1024, W=2048, vbs=16, steps=2, R=1, seed=2, controlnet=True),
+}
+LOOP_KW = dict(guidance_scale=10.0, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000, cosine_scale=10.0,
+               repaint_sampling=True)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def embed_fn(xl, cross_dim=64, pooled_dim=32):
+    (un, pun), (co, pco) = synthetic_text_embeds(1, cross_dim=cross_dim, pooled_dim=pooled_dim, xl=xl)
+    state = {"n": 0}
+
+    def fn(_):
+        state["n"] += 1
+        return (un, pun) if state["n"] % 2 == 1 else (co, pco)
+
+    return fn
+
+
+def build_small(sd, controlnet=False, seed=0):
+    """fp32 CPU master copies (unet, vae, controlnet|None) of the reduced-width real architectures."""
+    from elasticdiffusion_official_amd.models import build_models
+    mods = build_models(sd, device="cpu", dtype=torch.float32, controlnet=controlnet, small=True, seed=seed)
+    return mods if controlnet else mods + (None,)
+
+
+class OnDevice(nn.Module):
+    """Lets the CPU oracle loop drive a model that lives on the GPU in another dtype: inputs are moved over, the
+    output comes back as fp32 CPU tensors.  Only the call PATTERN is the oracle's; the arithmetic is the GPU model's."""
+
+    def __init__(self, mod, device, dtype):
+        super().__init__()
+        self.mod = copy.deepcopy(mod).to(device, dtype).eval()
+        self.config = mod.config
+        self.dev, self.dt = device, dtype
+        if hasattr(mod, "add_embedding"):
+            self.add_embedding = mod.add_embedding
+
+    def _mv(self, v):
+        if torch.is_tensor(v):
+            return v.to(self.dev, self.dt if v.is_floating_point() else None)
+        if isinstance(v, dict):
+            return {k: self._mv(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return type(v)(self._mv(x) for x in v)
+        return v
+
+    @torch.no_grad()
+    def forward(self, x, t, **kw):
+        out = self.mod(self._mv(x), torch.as_tensor(t).to(self.dev), **{k: self._mv(v) for k, v in kw.items()})
+        if isinstance(out, dict):
+            return {"sample": out["sample"].float().cpu()}
+        down, mid = out
+        return [d.float().cpu() for d in down], mid.float().cpu()
+
+
+def run_oracle(case, unet, vae, cn):
+    """The oracle loop on the CPU -> (per-timestep latents, rng tail)."""
+    c = REAL_CASES[case] if isinstance(case, str) else case
+    xl = c["sd"].startswith("XL")
+    orc = ElasticOracle(unet, vae, DDIMOracle(), embed_fn(xl), sd_version=c["sd"], view_batch_size=c["vbs"],
+                        pooled_dim=32 if xl else None, controlnet=cn)
+    kw = dict(LOOP_KW)
+    if cn is not None:
+        ds = orc.get_downsample_size(c["H"], c["W"])
+        kw.update(condition_image=cases.synthetic_condition(ds[0] * 8, ds[1] * 8), controlnet_conditioning_scale=0.2)
+    orc.seed_everything(c["seed"])
+    trace = []
+    orc.generate_latent("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"], resampling_steps=c["R"],
+                        trace=trace, **kw)
+    return trace, torch.rand(4)
+
+
+def run_product(case, unet, vae, cn, dtype, device="cuda:0"):
+    """The HIP product path with copies of the given modules on the GPU (UNet/ControlNet in ``dtype``, VAE fp32)."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    c = REAL_CASES[case] if isinstance(case, str) else case
+    xl = c["sd"].startswith("XL")
+    pipe = ElasticDiffusion(device, c["sd"], view_batch_size=c["vbs"], unet=copy.deepcopy(unet).to(dtype),
+                            vae=copy.deepcopy(vae), controlnet=None if cn is None else copy.deepcopy(cn).to(dtype),
+                            text_encoder=embed_fn(xl))
+    kw = dict(LOOP_KW)
+    if cn is not None:
+        ds = pipe.get_downsample_size(c["H"], c["W"])
+        kw.update(condition_image=cases.synthetic_condition(ds[0] * 8, ds[1] * 8), controlnet_conditioning_scale=0.2)
+    pipe.seed_everything(c["seed"])
+    trace = []
+    pipe.generate_latents("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                          resampling_steps=c["R"], trace=trace, **kw)
+    tail = torch.rand(4)
+    return [z.cpu() for z in trace], tail, pipe
+
+
+def drift_report(case, dtype=torch.bfloat16, device="cuda:0", with_fp32=True, with_batching=True):
+    """-> dict of per-timestep rel-L2 lists (see module docstring) + RNG-tail equality flags."""
+    c = REAL_CASES[case] if isinstance(case, str) else case
+    unet, vae, cn = build_small(c["sd"], controlnet=bool(c.get("controlnet")))
+    want, tail = run_oracle(c, unet, vae, cn)
+    out = {"case": case if isinstance(case, str) else "custom", "steps": c["steps"], "R": c["R"]}
+    if with_fp32:
+        got, t32, _ = run_product(c, unet, vae, cn, torch.float32, device)
+        out["fp32"] = [rel_l2(a, b) for a, b in zip(got, want)]
+        out["fp32_rng_tail_equal"] = bool(torch.equal(t32, tail))
+    got16, t16, pipe = run_product(c, unet, vae, cn, dtype, device)
+    out["bf16"] = [rel_l2(a, b) for a, b in zip(got16, want)]
+    out["bf16_rng_tail_equal"] = bool(torch.equal(t16, tail))
+    out["graphs"] = pipe._runner.stats()
+    if with_batching:
+        ref_pattern, _ = run_oracle(c, OnDevice(unet, device, dtype), vae, None if cn is None else OnDevice(cn, device, dtype))
+        out["batching"] = [rel_l2(a, b) for a, b in zip(got16, ref_pattern)]
+        out["ref_pattern_vs_fp32"] = [rel_l2(a, b) for a, b in zip(ref_pattern, want)]
+    return out

@@ -64,3 +64,35 @@ def test_generate_image_bit_identical(sd, H, W, steps, R, vbs, seed, patch, tile
     assert torch.equal(info["latent"], cap["z"])
     assert torch.equal(img, cap["img"])
     assert torch.equal(torch.rand(3), ref_tail)
+
+
+@pytest.mark.parametrize("case", ["cfg2_sd_512x1024", "cfg3_xl_1024x2048"])
+def test_real_architecture_oracle_leg_is_the_reference(case):
+    """tests/realarch.py's CPU leg (oracle + the repo's real reduced-width UNet/VAE modules) against the REAL reference
+    driving the same module objects: bit-identical latents after every step, identical RNG end state.  This pins the
+    oracle side of the -m gpu real-architecture parity tests to the reference itself."""
+    from oracle.ddim import DDIMOracle
+    from tests import realarch as R
+    from tests.golden.ref_loader import make_reference_pipeline
+
+    c = R.REAL_CASES[case]
+    xl = c["sd"].startswith("XL")
+    unet, vae, _ = R.build_small(c["sd"])
+    want, tail = R.run_oracle(case, unet, vae, None)
+
+    pipe, ref = make_reference_pipeline(unet, vae, DDIMOracle(), R.embed_fn(xl), sd_version=c["sd"],
+                                        view_batch_size=c["vbs"], pooled_dim=32)
+    pipe.random_downasmple_pre = {}
+    cap = {}
+
+    def grab(z):  # skip the (slow, irrelevant here) CPU VAE decode: keep the final latent, hand back a dummy image
+        cap["z"] = z.clone()
+        return torch.zeros(z.shape[0], 3, 8, 8)
+
+    pipe.decode_latents = grab
+    pipe.seed_everything(c["seed"])
+    pipe.generate_image(prompts="p", negative_prompts="", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                        resampling_steps=c["R"], progress=lambda it: it, rrg_scherduler_cls=ref.CosineScheduler,
+                        **R.LOOP_KW)
+    assert torch.equal(cap["z"], want[-1])
+    assert torch.equal(torch.rand(4), tail)
