@@ -75,15 +75,26 @@ __device__ __forceinline__ Welford merge(Welford a, Welford b) {
 
 #define GN_THREADS 512
 
+// ``cb`` (optional): per-channel bias of this (sample, group), cb[c - g*cpg]; the normalised tensor is
+// round16(x + cb[c]) -- what torch's 16-bit `h + temb[:, :, None, None]` (ResnetBlock2D) hands to norm2.
 template <typename T>
-__device__ __forceinline__ void group_stats(const uint16_t* __restrict__ chunk, int64_t len, float eps, float& mean, float& rstd) {
+__device__ __forceinline__ float biased(uint16_t x, float cb, bool has_cb) {
+  float f = T::to_f32(x);
+  return has_cb ? T::to_f32(T::from_f32(f + cb)) : f;
+}
+
+template <typename T>
+__device__ __forceinline__ void group_stats(const uint16_t* __restrict__ chunk, int64_t len, int HW,
+                                            const uint16_t* __restrict__ cb, float eps, float& mean, float& rstd) {
   // pass 1: per-thread sum / sum of squares over 16-byte vectors (few hundred elements per thread), then Chan merge
   float s = 0.f, ss = 0.f, cnt = 0.f;
+  const bool has_cb = cb != nullptr;
   for (int64_t i = (int64_t)threadIdx.x * 8; i < len; i += GN_THREADS * 8) {
     U16x8 v = *reinterpret_cast<const U16x8*>(chunk + i);
+    const float cbv = has_cb ? T::to_f32(cb[i / HW]) : 0.f;  // HW % 8 == 0: a vector never straddles channels
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float f = T::to_f32(v.v[e]);
+      float f = biased<T>(v.v[e], cbv, has_cb);
       s += f;
       ss += f * f;
     }
@@ -121,23 +132,27 @@ __device__ __forceinline__ void group_stats(const uint16_t* __restrict__ chunk, 
 template <typename T, bool ACT, bool TOKENS>
 __global__ void __launch_bounds__(GN_THREADS)
 k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
-            uint16_t* __restrict__ out, int C, int HW, int G, float eps) {
+            const uint16_t* __restrict__ chan_bias, uint16_t* __restrict__ out, int C, int HW, int G, float eps) {
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const int64_t len = (int64_t)cpg * HW;
   const uint16_t* chunk = x + ((int64_t)n * C + (int64_t)g * cpg) * HW;
+  const uint16_t* cb = chan_bias ? chan_bias + (int64_t)n * C + (int64_t)g * cpg : nullptr;
+  const bool has_cb = cb != nullptr;
   float mean, rstd;
-  group_stats<T>(chunk, len, eps, mean, rstd);
+  group_stats<T>(chunk, len, HW, cb, eps, mean, rstd);
   if (!TOKENS) {
     uint16_t* dst = out + ((int64_t)n * C + (int64_t)g * cpg) * HW;
     for (int64_t i = (int64_t)threadIdx.x * 8; i < len; i += GN_THREADS * 8) {
-      int c = g * cpg + (int)(i / HW);  // HW % 8 == 0: a vector never straddles channels
+      int cl = (int)(i / HW);  // HW % 8 == 0: a vector never straddles channels
+      int c = g * cpg + cl;
       float a = rstd * T::to_f32(gamma[c]);
       float b = fmaf(-a, mean, T::to_f32(beta[c]));
+      const float cbv = has_cb ? T::to_f32(cb[cl]) : 0.f;
       U16x8 v = *reinterpret_cast<const U16x8*>(chunk + i), o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float y = T::to_f32(T::from_f32(fmaf(a, T::to_f32(v.v[e]), b)));  // torch rounds the norm output first
+        float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(v.v[e], cbv, has_cb), b)));  // torch rounds the norm output first
         o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
       }
       *reinterpret_cast<U16x8*>(dst + i) = o;
@@ -154,7 +169,8 @@ k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
           int c = g * cpg + cc + e;
           float a = rstd * T::to_f32(gamma[c]);
           float b = fmaf(-a, mean, T::to_f32(beta[c]));
-          float y = T::to_f32(T::from_f32(fmaf(a, T::to_f32(chunk[(int64_t)(cc + e) * HW + p]), b)));
+          const float cbv = has_cb ? T::to_f32(cb[cc + e]) : 0.f;
+          float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(chunk[(int64_t)(cc + e) * HW + p], cbv, has_cb), b)));
           o4[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
         }
         uint2 pk;
@@ -339,6 +355,110 @@ k_layernorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
   }
 }
 
+// ---- residual add + LayerNorm: sum = round16(a + b) (torch's 16-bit add), out = LayerNorm(sum) -------------------------
+// BasicTransformerBlock: `x = attn(norm(x)) + x` followed by the next `norm(x)`: one read of each addend, one write of
+// the new residual stream and one of its normalisation, instead of add (2r + 1w) + LayerNorm (1r + 1w).
+template <typename T>
+__global__ void __launch_bounds__(64 * LN_ROWS_PER_BLOCK)
+k_add_layernorm(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, const uint16_t* __restrict__ gamma,
+                const uint16_t* __restrict__ beta, uint16_t* __restrict__ sum_out, uint16_t* __restrict__ out, int64_t M,
+                int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int VC = D >> 3;
+  const uint16_t* ar = a + row * (int64_t)D;
+  const uint16_t* br = b + row * (int64_t)D;
+  uint16_t* sr = sum_out + row * (int64_t)D;
+  float v[LN_MAX_IT][8];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < LN_MAX_IT; ++it) {
+    int vc = lane + it * 64;
+    if (vc < VC) {
+      U16x8 ua = *reinterpret_cast<const U16x8*>(ar + (vc << 3));
+      U16x8 ub = *reinterpret_cast<const U16x8*>(br + (vc << 3));
+      U16x8 us;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        us.v[e] = T::from_f32(T::to_f32(ua.v[e]) + T::to_f32(ub.v[e]));
+        v[it][e] = T::to_f32(us.v[e]);
+        s += v[it][e];
+      }
+      *reinterpret_cast<U16x8*>(sr + (vc << 3)) = us;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < LN_MAX_IT; ++it) {
+    int vc = lane + it * 64;
+    if (vc < VC) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = v[it][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = rsqrtf(q / (float)D + eps);
+  uint16_t* orow = out + row * (int64_t)D;
+#pragma unroll
+  for (int it = 0; it < LN_MAX_IT; ++it) {
+    int vc = lane + it * 64;
+    if (vc < VC) {
+      U16x8 g = *reinterpret_cast<const U16x8*>(gamma + (vc << 3));
+      U16x8 bt = *reinterpret_cast<const U16x8*>(beta + (vc << 3));
+      U16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o.v[e] = T::from_f32(fmaf(T::to_f32(g.v[e]), rstd * (v[it][e] - mean), T::to_f32(bt.v[e])));
+      *reinterpret_cast<U16x8*>(orow + (vc << 3)) = o;
+    }
+  }
+}
+
+// ---- out[n,c,p] = x[n,c,p] + tok[n,p,c]: the residual add that closes a Transformer2DModel ----------------------------
+// (diffusers: `hidden_states.reshape(B,H,W,C).permute(0,3,1,2) + residual`): a 64 x 64 (p, c) tile goes through LDS so
+// that the token-major read and the channel-major read/write are all 16-byte coalesced.  torch ran this as a strided
+// elementwise kernel (elementwise_kernel_manual_unroll, 3.2 % of GPU time in the round-1 profile).
+#define TA_TILE 64
+#define TA_LD (TA_TILE + 2)  // 132 B rows: the column reads of 8 consecutive p hit 8 different dwords mod 32
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_tokens_add_nchw(const uint16_t* __restrict__ x, const uint16_t* __restrict__ tok, uint16_t* __restrict__ out, int C,
+                  int HW) {
+  __shared__ uint16_t tile[TA_TILE * TA_LD];  // [p][c]
+  const int n = blockIdx.z, c0 = blockIdx.y * TA_TILE, p0 = blockIdx.x * TA_TILE;
+  const uint16_t* tb = tok + ((int64_t)n * HW + p0) * C + c0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx = threadIdx.x + 256 * i;  // 64 rows x 8 vectors
+    int p = idx >> 3, cv = (idx & 7) * 8;
+    U16x8 v = *reinterpret_cast<const U16x8*>(tb + (int64_t)p * C + cv);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&tile[p * TA_LD + cv]);  // rows are 4-byte aligned (132 B pitch)
+    dst[0] = (uint32_t)v.v[0] | ((uint32_t)v.v[1] << 16);
+    dst[1] = (uint32_t)v.v[2] | ((uint32_t)v.v[3] << 16);
+    dst[2] = (uint32_t)v.v[4] | ((uint32_t)v.v[5] << 16);
+    dst[3] = (uint32_t)v.v[6] | ((uint32_t)v.v[7] << 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int idx = threadIdx.x + 256 * i;  // 64 channels x 8 vectors of 8 tokens
+    int c = idx >> 3, pv = (idx & 7) * 8;
+    int64_t off = ((int64_t)n * C + c0 + c) * HW + p0 + pv;
+    U16x8 xv = *reinterpret_cast<const U16x8*>(x + off), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = T::from_f32(T::to_f32(xv.v[e]) + T::to_f32(tile[(pv + e) * TA_LD + c]));
+    *reinterpret_cast<U16x8*>(out + off) = o;
+  }
+}
+
 inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -359,15 +479,16 @@ int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* strea
   return done();
 }
 
-int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int N, int C, int HW, int G,
-                 float eps, int act_silu, int tokens_out, void* stream) {
+int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* chan_bias, void* out, int dtype, int N,
+                 int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream) {
   if (N == 0) return 0;
   if (C % G != 0 || HW % 8 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
   if (tokens_out && (C / G) % 4 != 0) return (int)hipErrorInvalidValue;
   dim3 grid(N * G), block(GN_THREADS);
   hipStream_t s = (hipStream_t)stream;
 #define GN_LAUNCH(T, A, K) \
-  k_groupnorm<T, A, K><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)out, C, HW, G, eps)
+  k_groupnorm<T, A, K><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, \
+                                              (const uint16_t*)chan_bias, (uint16_t*)out, C, HW, G, eps)
 #define GN_DISPATCH(T)                         \
   if (act_silu && !tokens_out) GN_LAUNCH(T, true, false);  \
   else if (act_silu) GN_LAUNCH(T, true, true);  \
@@ -440,6 +561,43 @@ int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, 
   else if (dtype == ED_F16)
     k_layernorm<F16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta,
                                            (uint16_t*)out, M, D, eps);
+  else
+    return (int)hipErrorInvalidValue;
+  return done();
+}
+
+int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
+                     int dtype, int64_t M, int D, float eps, void* stream) {
+  if (M == 0) return 0;
+  if (D % 8 != 0 || D > 64 * 8 * LN_MAX_IT ||
+      (((uintptr_t)a | (uintptr_t)b | (uintptr_t)sum_out | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
+    return (int)hipErrorInvalidValue;
+  int64_t blocks = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+  if (blocks > 0x7fffffff) return (int)hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks), block(64 * LN_ROWS_PER_BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ED_BF16)
+    k_add_layernorm<BF16><<<grid, block, 0, s>>>((const uint16_t*)a, (const uint16_t*)b, (const uint16_t*)gamma,
+                                                (const uint16_t*)beta, (uint16_t*)sum_out, (uint16_t*)out, M, D, eps);
+  else if (dtype == ED_F16)
+    k_add_layernorm<F16><<<grid, block, 0, s>>>((const uint16_t*)a, (const uint16_t*)b, (const uint16_t*)gamma,
+                                               (const uint16_t*)beta, (uint16_t*)sum_out, (uint16_t*)out, M, D, eps);
+  else
+    return (int)hipErrorInvalidValue;
+  return done();
+}
+
+int ed_tokens_add_nchw(const void* x, const void* tokens, void* out, int dtype, int N, int C, int HW, void* stream) {
+  if (N == 0) return 0;
+  if (C % TA_TILE != 0 || HW % TA_TILE != 0 || N > 65535 || C / TA_TILE > 65535 ||
+      (((uintptr_t)x | (uintptr_t)tokens | (uintptr_t)out) & 15u))
+    return (int)hipErrorInvalidValue;
+  dim3 grid(HW / TA_TILE, C / TA_TILE, N), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ED_BF16)
+    k_tokens_add_nchw<BF16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)tokens, (uint16_t*)out, C, HW);
+  else if (dtype == ED_F16)
+    k_tokens_add_nchw<F16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)tokens, (uint16_t*)out, C, HW);
   else
     return (int)hipErrorInvalidValue;
   return done();

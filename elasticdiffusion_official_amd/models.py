@@ -40,10 +40,16 @@ def _fusable_nhwc(x):
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def group_norm_act(norm, x, silu=False, tokens=False):
-    """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout].  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
+def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None):
+    """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout] of ``x`` (or of ``x + chan_bias[:, :, None, None]``: the
+    time-embedding add of ResnetBlock2D folded into the kernel).  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
     N, C, H, W = x.shape
     cpg = C // norm.num_groups
+    if chan_bias is not None and not (FUSED_TEMB_ADD and _fusable(x) and (H * W) % 8 == 0 and not tokens):
+        x, chan_bias = x + chan_bias[:, :, None, None], None
+    if chan_bias is not None:
+        from . import ops
+        return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, chan_bias=chan_bias.contiguous())
     if _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8:
         from . import ops
         y = ops.groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
@@ -58,6 +64,26 @@ def group_norm_act(norm, x, silu=False, tokens=False):
 
 
 FUSED_LAYERNORM = True
+FUSED_TEMB_ADD = True      # ResnetBlock2D: h + temb folded into norm2 (ed_groupnorm chan_bias)
+FUSED_ADD_LAYERNORM = True  # BasicTransformerBlock: residual add + next LayerNorm in one kernel (ed_add_layernorm)
+FUSED_TOKENS_ADD = True     # Transformer2DModel: tokens -> NCHW + residual in one kernel (ed_tokens_add_nchw)
+FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit) instead of SDPA / AOTriton
+FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
+# A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
+for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
+    if _name not in globals() or not isinstance(globals()[_name], bool):
+        raise RuntimeError(f"ED_DISABLE: unknown switch {_name!r}")
+    globals()[_name] = False
+
+
+def fused_unet_entry_points():
+    """C-ABI entry points a 16-bit UNet forward reaches with the current switches (the real-architecture parity test
+    checks that they were actually launched, i.e. that no torch fallback silently took over)."""
+    on = [("ed_groupnorm", FUSED_KERNELS), ("ed_geglu", FUSED_KERNELS), ("ed_layernorm", FUSED_KERNELS and FUSED_LAYERNORM),
+          ("ed_flash_attention", FUSED_KERNELS and FLASH_ATTENTION),
+          ("ed_add_layernorm", FUSED_KERNELS and FUSED_ADD_LAYERNORM),
+          ("ed_tokens_add_nchw", FUSED_KERNELS and FUSED_TOKENS_ADD)]
+    return {n for n, flag in on if flag}
 
 
 def layer_norm(norm, x):
@@ -67,6 +93,17 @@ def layer_norm(norm, x):
         from . import ops
         return ops.layernorm(x, norm.weight, norm.bias, norm.eps)
     return norm(x)
+
+
+def add_layer_norm(norm, a, b):
+    """(a + b, LayerNorm(a + b)).  HIP: ed_add_layernorm; torch otherwise."""
+    D = a.shape[-1]
+    if (FUSED_ADD_LAYERNORM and _fusable(a) and _fusable(b) and a.shape == b.shape and D % 8 == 0 and D <= 2048
+            and norm.elementwise_affine):
+        from . import ops
+        return ops.add_layernorm(a, b, norm.weight, norm.bias, norm.eps)
+    s = a + b
+    return s, layer_norm(norm, s)
 
 
 class ModelOutput(dict):
@@ -113,9 +150,8 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb=None):
         h = self.conv1(group_norm_act(self.norm1, x, silu=True))
-        if self.time_emb_proj is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        a = group_norm_act(self.norm2, h, silu=True)
+        tb = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
+        a = group_norm_act(self.norm2, h, silu=True, chan_bias=tb)  # GroupNorm(h + temb) (+SiLU)
         sc = self.conv_shortcut
         if sc is not None and SHORTCUT_AS_GEMM and _fusable(x):
             # out = W_sc x + (conv2(a) + b_conv2 + b_sc): the shortcut bias rides on conv2's bias, the residual sum is
@@ -139,8 +175,35 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(cross_dim or dim, inner, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Dropout(0.0)])
 
+    def _fused_weight(self, names):
+        """cat of the projection weights (bias-free in every SD / SDXL attention), rebuilt when a weight changes."""
+        mods = [getattr(self, n) for n in names]
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype, str(m.weight.device)) for m in mods)
+        cache = self.__dict__.setdefault("_fused", {})
+        if cache.get(names, (None, None))[0] != key:
+            cache[names] = (key, torch.cat([m.weight.detach() for m in mods], dim=0).contiguous())
+        return cache[names][1]
+
     def forward(self, x, context=None):
         B, N, _ = x.shape
+        inner = self.to_q.out_features
+        if (FLASH_ATTENTION and _fusable(x) and inner == self.heads * 64 and self.to_q.bias is None
+                and (context is None or (_fusable(context) and context.dtype == x.dtype))):
+            from . import ops
+            if context is None:
+                if FUSED_QKV:
+                    qkv = F.linear(x, self._fused_weight(("to_q", "to_k", "to_v")))
+                    q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
+                else:
+                    q, k, v = self.to_q(x), self.to_k(x), self.to_v(x)
+            else:
+                q = self.to_q(x)
+                if FUSED_QKV:
+                    kv = F.linear(context, self._fused_weight(("to_k", "to_v")))
+                    k, v = kv[..., :inner], kv[..., inner:]
+                else:
+                    k, v = self.to_k(context), self.to_v(context)
+            return self.to_out[0](ops.flash_attention(q, k, v, self.heads))
         ctx = x if context is None else context
         q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
@@ -182,10 +245,16 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def forward(self, x, context):
-        x = self.attn1(layer_norm(self.norm1, x)) + x
-        x = self.attn2(layer_norm(self.norm2, x), context) + x
-        return self.ff(layer_norm(self.norm3, x)) + x
+    def forward(self, x, context, pending=None):
+        """-> (ff_out, x): the block's output is ``ff_out + x``; the caller either hands the pair to the next block
+        (whose norm1 then runs fused with that add) or sums it.  ``pending``: the previous block's ff_out."""
+        if pending is not None:
+            x, h = add_layer_norm(self.norm1, pending, x)                 # x = prev_ff + x ; norm1(x)
+        else:
+            h = layer_norm(self.norm1, x)
+        x, h = add_layer_norm(self.norm2, self.attn1(h), x)               # x = attn1(norm1(x)) + x ; norm2(x)
+        x, h = add_layer_norm(self.norm3, self.attn2(h, context), x)      # x = attn2(norm2(x)) + x ; norm3(x)
+        return self.ff(h), x
 
 
 class Transformer2DModel(nn.Module):
@@ -203,10 +272,16 @@ class Transformer2DModel(nn.Module):
             h = self.proj_in(group_norm_act(self.norm, x, tokens=True))
         else:
             h = self.proj_in(group_norm_act(self.norm, x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        pend = None
         for blk in self.transformer_blocks:
-            h = blk(h, context)
+            pend, h = blk(h, context, pend)
+        h = pend + h
         if self.linear_proj:
-            h = self.proj_out(h).view(B, H, W, C).permute(0, 3, 1, 2)
+            h = self.proj_out(h)
+            if (FUSED_TOKENS_ADD and _fusable(x) and _fusable(h) and C % 64 == 0 and (H * W) % 64 == 0):
+                from . import ops
+                return ops.tokens_add_nchw(x, h)  # x + h^T in one pass through an LDS tile
+            h = h.view(B, H, W, C).permute(0, 3, 1, 2)
         else:
             h = self.proj_out(h.view(B, H, W, C).permute(0, 3, 1, 2))
         return x + h  # x first: the sum keeps x's NCHW layout (a permuted first operand would make it channels-last)

@@ -257,12 +257,16 @@ def geglu(x2, inner):
     return out
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False):
-    """x [N,C,H,W] NCHW 16-bit -> GroupNorm(+SiLU) as [N,C,H,W], or [N,H*W,C] when ``tokens``."""
+def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False, chan_bias=None):
+    """x [N,C,H,W] NCHW 16-bit -> GroupNorm(+SiLU) as [N,C,H,W], or [N,H*W,C] when ``tokens``.
+    ``chan_bias`` [N,C] (optional): normalise round16(x + chan_bias[:, :, None, None]) instead of x."""
     N, C, H, W = x.shape
+    if chan_bias is not None:
+        assert tuple(chan_bias.shape) == (N, C)
     out = torch.empty((N, H * W, C) if tokens else (N, C, H, W), dtype=x.dtype, device=x.device)
     _call("ed_groupnorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
-          _dev(out, None, "out"), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), int(tokens), _stream())
+          _opt(chan_bias, x.dtype, "chan_bias"), _dev(out, None, "out"), _code(x, "x"), N, C, H * W, groups, float(eps),
+          int(silu), int(tokens), _stream())
     return out
 
 
@@ -287,4 +291,50 @@ def layernorm(x, gamma, beta, eps):
     out = torch.empty_like(x)
     _call("ed_layernorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
           _dev(out, None, "out"), _code(x, "x"), x.numel() // D, D, float(eps), _stream())
+    return out
+
+
+def add_layernorm(a, b, gamma, beta, eps):
+    """a, b [..., D] contiguous 16-bit -> (a + b, LayerNorm(a + b)); the sum is rounded to the 16-bit type first."""
+    D = a.shape[-1]
+    assert a.shape == b.shape and a.dtype == b.dtype
+    s, out = torch.empty_like(a), torch.empty_like(a)
+    _call("ed_add_layernorm", _dev(a, None, "a"), _dev(b, a.dtype, "b"), _dev(gamma, a.dtype, "gamma"),
+          _dev(beta, a.dtype, "beta"), _dev(s, None, "sum"), _dev(out, None, "out"), _code(a, "a"), a.numel() // D, D,
+          float(eps), _stream())
+    return s, out
+
+
+def tokens_add_nchw(x, tokens):
+    """x [N,C,H,W] + tokens [N,H*W,C] (16-bit, contiguous) -> [N,C,H,W]: the residual add closing a transformer."""
+    N, C, H, W = x.shape
+    assert tuple(tokens.shape) == (N, H * W, C) and tokens.dtype == x.dtype
+    out = torch.empty_like(x)
+    _call("ed_tokens_add_nchw", _dev(x, None, "x"), _dev(tokens, None, "tokens"), _dev(out, None, "out"), _code(x, "x"),
+          N, C, H * W, _stream())
+    return out
+
+
+FLASH_V_PATH = 0  # 0 = ds_read_b64_tr_b16 from a row-major V tile, 1 = V^T tile in LDS (A/B switch, same results)
+
+
+def flash_attention(q, k, v, heads, v_path=None):
+    """q [B,Nq,H*64], k / v [B,Nk,H*64] 16-bit (last dim contiguous; batch / token strides free, so column slices of a
+    fused QKV projection are fine) -> softmax(q k^T / 8) v as a contiguous [B,Nq,H*64] tensor.  See ed_flash_attention."""
+    B, Nq, HD = q.shape
+    Nk = k.shape[1]
+    if HD != heads * 64 or k.shape != (B, Nk, HD) or v.shape != (B, Nk, HD):
+        _reject(f"flash_attention: head_dim must be 64 and shapes consistent (q {tuple(q.shape)}, k {tuple(k.shape)}, "
+                f"v {tuple(v.shape)}, heads {heads})")
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != q.dtype or t.stride(2) != 1:
+            _reject(f"flash_attention: {name} must be a 16-bit tensor on the MI355X with unit last stride; no CPU fallback")
+        if _LAUNCH["device"] is None:
+            _LAUNCH["device"] = t.device
+        elif _LAUNCH["device"] != t.device:
+            _reject(f"flash_attention: {name} lives on {t.device}, q on {_LAUNCH['device']}")
+    out = torch.empty(B, Nq, HD, dtype=q.dtype, device=q.device)
+    _call("ed_flash_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _code(q, "q"), B, heads, Nq, Nk,
+          64, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+          0.125, FLASH_V_PATH if v_path is None else int(v_path), _stream())
     return out

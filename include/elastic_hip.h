@@ -185,10 +185,12 @@ int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* strea
  * ed_groupnorm -- GroupNorm over NCHW 16-bit activations with optional fused SiLU (ResnetBlock2D norm1/norm2,
  * conv_norm_out) and optional [N,HW,C] token-layout output (Transformer2DModel.norm + the permute that follows).
  *   x dtype [N,C,HW] (NCHW contiguous), gamma/beta dtype [C], out dtype [N,C,HW] or [N,HW,C];
+ *   chan_bias dtype [N,C] or NULL: when given, the tensor that is normalised is round16(x + chan_bias[n,c]) -- the
+ *   time-embedding add `h + temb[:, :, None, None]` that precedes norm2 in ResnetBlock2D, folded into both passes;
  *   HW % 8 == 0, C % G == 0 (and (C/G) % 4 == 0 for tokens_out); dtype = ED_F16 | ED_BF16.
  */
-int ed_groupnorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int N, int C, int HW, int G,
-                 float eps, int act_silu, int tokens_out, void* stream);
+int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* chan_bias, void* out, int dtype, int N,
+                 int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream);
 
 /*
  * ed_layernorm -- LayerNorm over the last dimension of [M, D] 16-bit activations (BasicTransformerBlock.norm1/2/3):
@@ -199,6 +201,21 @@ int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, 
                  void* stream);
 
 /*
+ * ed_add_layernorm -- residual add + LayerNorm in one pass (BasicTransformerBlock: `x = attn(norm(x)) + x` and the
+ * `norm(x)` that follows): sum_out = round16(a + b), out = LayerNorm(sum_out).  [M, D] 16-bit, same limits as
+ * ed_layernorm; sum_out may alias a or b.
+ */
+int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
+                     int dtype, int64_t M, int D, float eps, void* stream);
+
+/*
+ * ed_tokens_add_nchw -- out[n,c,p] = x[n,c,p] + tokens[n,p,c]: the residual add that closes a Transformer2DModel
+ * (token layout back to NCHW), through a 64 x 64 LDS tile so both layouts are read / written with 16-byte vectors.
+ *   x, out dtype [N,C,HW]; tokens dtype [N,HW,C]; C % 64 == 0, HW % 64 == 0; dtype = ED_F16 | ED_BF16.
+ */
+int ed_tokens_add_nchw(const void* x, const void* tokens, void* out, int dtype, int N, int C, int HW, void* stream);
+
+/*
  * ed_groupnorm_nhwc -- the same GroupNorm [+ SiLU] for channels-last activations: x / out dtype [N, HW, C] (the memory
  * of an NCHW tensor in torch.channels_last format, which is also the transformer's token layout).  Three launches
  * (partial sums, finalise in double, vectorised apply); `workspace` is caller-owned fp32 scratch of
@@ -207,6 +224,21 @@ int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, 
 int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
                       int C, int HW, int G, float eps, int act_silu, void* stream);
 int64_t ed_groupnorm_nhwc_workspace(int N, int C, int HW, int G);
+
+/*
+ * ed_flash_attention -- fused attention forward of the UNet's transformer blocks (what diffusers' AttnProcessor2_0
+ * does with F.scaled_dot_product_attention inside `self.unet(...)`, ED:422-426): out = softmax(scale * Q K^T) V per
+ * (batch, head), never materialising the Nq x Nk score matrix.  MFMA 32x32x16 (bf16 / f16), online softmax in fp32.
+ *   q   dtype [B, Nq, H, 64]   element strides q_sb (batch), q_sn (token); head stride 64, unit d stride
+ *   k,v dtype [B, Nk, H, 64]   strides likewise (q/k/v may be column slices of one fused projection output)
+ *   out dtype [B, Nq, H, 64]   strides o_sb, o_sn
+ *   head_dim must be 64; dtype = ED_F16 | ED_BF16; q/k/v 16-byte aligned with strides % 8 == 0, out 8-byte aligned
+ *   with strides % 4 == 0.  Nk need not be a multiple of the 64-key tile (cross-attention: 77 text tokens).
+ *   v_path: 0 = V transposed on the fly by ds_read_b64_tr_b16, 1 = V^T tile staged in LDS (same result).
+ */
+int ed_flash_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,
+                       int head_dim, int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,
+                       int64_t o_sb, int64_t o_sn, float scale, int v_path, void* stream);
 
 #ifdef __cplusplus
 }

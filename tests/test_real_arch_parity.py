@@ -63,6 +63,5 @@ def test_fused_kernels_are_inside_the_bf16_loop():
         R.run_product(c, unet, vae, cn, torch.bfloat16)
     finally:
         ops._call = orig
-    need = {"ed_groupnorm", "ed_geglu", "ed_layernorm", "ed_pick_assemble", "ed_gather_views"}
-    need |= set(getattr(M, "FUSED_UNET_ENTRY_POINTS", ()))
+    need = {"ed_pick_assemble", "ed_gather_views"} | M.fused_unet_entry_points()
     assert need <= seen, sorted(need - seen)

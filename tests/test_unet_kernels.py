@@ -171,3 +171,123 @@ def test_unet_fused_vs_unfused_close():
         M.FUSED_KERNELS, M.SHORTCUT_AS_GEMM = saved  # module switches must not leak into later tests
     rel = float((a - b).norm() / b.norm())
     assert a.is_contiguous() and rel < 2e-2, rel
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: flash attention, fused residual adds
+# ---------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, H):
+    """fp32 PyTorch reference of the op: softmax(q k^T / sqrt(64)) v per head, on the same 16-bit inputs."""
+    B, Nq, HD = q.shape
+    qf, kf, vf = (t.float().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
+    s = qf @ kf.transpose(-1, -2) * 0.125
+    return (torch.softmax(s, dim=-1) @ vf).transpose(1, 2).reshape(B, Nq, HD)
+
+
+@pytest.mark.parametrize("v_path", [0, 1])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 10, 4096, 4096), (3, 20, 1024, 1024), (2, 20, 1024, 77), (1, 10, 4096, 77),
+                                       (2, 2, 256, 256), (1, 4, 64, 64), (1, 1, 100, 77), (2, 3, 200, 333), (1, 2, 1, 1)])
+def test_flash_attention(dtype, B, H, Nq, Nk, v_path):
+    """ed_flash_attention vs the fp32 reference; it must be as accurate as the library kernel it replaces (SDPA)."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(Nq * 7 + Nk)
+    q, k, v = (torch.randn(B, n, H * 64, device=DEV, generator=g).mul(s).to(dtype) for n, s in ((Nq, 1.5), (Nk, 1.5), (Nk, 1.0)))
+    got = ops.flash_attention(q, k, v, H, v_path=v_path)
+    assert got.shape == (B, Nq, H * 64) and got.is_contiguous()
+    ref = _attn_ref(q, k, v, H)
+    sdpa = F.scaled_dot_product_attention(*(t.view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v)))
+    sdpa = sdpa.transpose(1, 2).reshape(B, Nq, H * 64)
+    err = float((got.float() - ref).abs().max())
+    err_sdpa = float((sdpa.float() - ref).abs().max())
+    rel = float((got.float() - ref).norm() / ref.norm())
+    rel_sdpa = float((sdpa.float() - ref).norm() / ref.norm())
+    print(f"flash {dtype} B{B} H{H} Nq{Nq} Nk{Nk} path{v_path}: max|err| {err:.2e} (sdpa {err_sdpa:.2e})  rel {rel:.2e} (sdpa {rel_sdpa:.2e})")
+    assert bool(torch.isfinite(got).all())
+    assert rel < 1.5 * rel_sdpa + 1e-4, (rel, rel_sdpa)
+    assert err < 3.0 * err_sdpa + 4e-3, (err, err_sdpa)
+
+
+def test_flash_attention_strided_inputs_and_outlier_rows():
+    """q/k/v as column slices of one fused projection output; one query row with a huge score (online-softmax rescale
+    path: the running max jumps by > 100 in a late tile) and one all-equal row."""
+    from elasticdiffusion_official_amd import ops
+    B, H, N = 2, 5, 640
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(B, N, 3 * H * 64, device=DEV, generator=g).to(torch.bfloat16)
+    q, k, v = qkv[..., :H * 64], qkv[..., H * 64:2 * H * 64], qkv[..., 2 * H * 64:]
+    k[0, 600, :64] = 12.0 * q[0, 5, :64].sign()   # query 5 of head 0 matches key 600 (10th tile) with score >> others
+    q[1, 7] = 0                                    # uniform attention for query 7 of batch 1
+    got = ops.flash_attention(q, k, v, H)
+    ref = _attn_ref(q, k, v, H)
+    assert float((got.float() - ref).abs().max()) < 3e-2
+    assert float((got[0, 5, :64].float() - v[0, 600, :64].float()).abs().max()) < 3e-2   # ~one-hot row
+    assert float((got[1, 7].float() - v[1].float().mean(0)).abs().max()) < 2e-2          # ~mean of V
+    for path in (0, 1):
+        again = ops.flash_attention(q.contiguous(), k.contiguous(), v.contiguous(), H, v_path=path)
+        assert torch.equal(again, got)  # strides and the V staging path do not change a single bit
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,D", [(4096, 640), (1000, 1280), (77, 2048), (5, 8), (3, 320)])
+def test_add_layernorm(dtype, M, D):
+    from elasticdiffusion_official_amd import ops
+    a = (torch.randn(M, D, device=DEV) * 2.1 + 0.4).to(dtype)
+    b = (torch.randn(M, D, device=DEV) * 0.7).to(dtype)
+    w = (1 + 0.2 * torch.randn(D, device=DEV)).to(dtype)
+    bb = (0.1 * torch.randn(D, device=DEV)).to(dtype)
+    s, out = ops.add_layernorm(a, b, w, bb, 1e-5)
+    assert torch.equal(s, a + b)                                   # torch's 16-bit add, bit for bit
+    assert torch.equal(out, ops.layernorm(a + b, w, bb, 1e-5))      # and exactly ed_layernorm of that sum
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 640, 64, 64), (2, 1280, 8, 8), (1, 64, 8, 16)])
+def test_tokens_add_nchw(dtype, N, C, H, W):
+    from elasticdiffusion_official_amd import ops
+    x = torch.randn(N, C, H, W, device=DEV).to(dtype)
+    tok = torch.randn(N, H * W, C, device=DEV).to(dtype)
+    got = ops.tokens_add_nchw(x, tok)
+    want = x + tok.view(N, H, W, C).permute(0, 3, 1, 2)
+    assert got.is_contiguous() and torch.equal(got, want.contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 640, 16, 16), (2, 64, 4, 2)])
+def test_groupnorm_with_channel_bias(dtype, N, C, H, W):
+    """ed_groupnorm(chan_bias=temb) == ed_groupnorm(x + temb[:, :, None, None]) bit for bit."""
+    from elasticdiffusion_official_amd import ops
+    x = (torch.randn(N, C, H, W, device=DEV) * 1.7 + 0.3).to(dtype)
+    cb = torch.randn(N, C, device=DEV).to(dtype)
+    w = (1 + 0.2 * torch.randn(C, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(C, device=DEV)).to(dtype)
+    got = ops.groupnorm(x, w, b, 32, 1e-5, silu=True, chan_bias=cb)
+    want = ops.groupnorm(x + cb[:, :, None, None], w, b, 32, 1e-5, silu=True)
+    assert torch.equal(got, want)
+
+
+def test_unet_round2_fusions_close():
+    """Whole (small, head_dim 64) UNet in bf16: flash attention + fused QKV + fused adds vs all of them off."""
+    from elasticdiffusion_official_amd import models as M
+    torch.manual_seed(0)
+    u = M.UNet2DConditionModel(**M.SMALL_UNET_CONFIGS["sdxl"]).to(DEV, torch.bfloat16).eval()
+    x = torch.randn(3, 4, 64, 64, device=DEV, dtype=torch.bfloat16)
+    e = torch.randn(3, 77, 64, device=DEV, dtype=torch.bfloat16)
+    kw = {"text_embeds": torch.randn(3, 32, device=DEV, dtype=torch.bfloat16), "time_ids": torch.zeros(3, 6, device=DEV)}
+    t = torch.tensor(500, device=DEV)
+    names = ("FLASH_ATTENTION", "FUSED_QKV", "FUSED_ADD_LAYERNORM", "FUSED_TOKENS_ADD", "FUSED_TEMB_ADD")
+    saved = {n: getattr(M, n) for n in names}
+    try:
+        with torch.no_grad():
+            a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+            for n in names:
+                setattr(M, n, False)
+            b = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+            ref = u.float()(x.float(), t, encoder_hidden_states=e.float(),
+                            added_cond_kwargs={k: v.float() for k, v in kw.items()})["sample"]
+    finally:
+        for n, v in saved.items():
+            setattr(M, n, v)
+    ra, rb = float((a - ref).norm() / ref.norm()), float((b - ref).norm() / ref.norm())
+    print(f"small SDXL UNet bf16 vs fp32: fused {ra:.3e}, unfused {rb:.3e}")
+    assert ra < 1.5 * rb + 1e-3, (ra, rb)

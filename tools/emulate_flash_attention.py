@@ -1,0 +1,153 @@
+"""Lane-level numpy emulation of csrc/attention_kernels.hip (index math only, fp64 arithmetic).
+
+There is no GPU in the build container, so the kernel's operand / accumulator index formulas are checked here against
+a plain softmax(QK^T)V before any GPU minute is spent: every LDS address, MFMA fragment slot and accumulator register
+below is computed with the SAME expressions the kernel uses, under the documented gfx950 layouts
+
+  v_mfma_f32_32x32x16:  A[i = lane&31][k = 8*(lane>>5) + j]   B[k = 8*(lane>>5) + j][n = lane&31]   j = 0..7
+                        D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]                        r = 0..15
+  ds_read_b64_tr_b16 :  within each 16-lane group, lane i supplies the address of 4 consecutive 16-bit elements =
+                        row (i>>2), columns 4*(i&3).. of a [4][16] block; lane i receives column i (4 rows).
+
+    python tools/emulate_flash_attention.py        -> prints max |err| for both V paths, ragged Nq / Nk included
+"""
+import numpy as np
+
+D, QB, KT, K_LD, V_LD_TR, V_LD_T = 64, 128, 64, 72, 96, 68
+
+
+def mfma_32x32x16(A, B, C):
+    """A, B: [64 lanes, 8]; C: [64 lanes, 16] -> D with the documented layouts."""
+    a = np.zeros((32, 16)), np.zeros((16, 32))
+    Am, Bm = a
+    for lane in range(64):
+        for j in range(8):
+            Am[lane & 31, 8 * (lane >> 5) + j] = A[lane, j]
+            Bm[8 * (lane >> 5) + j, lane & 31] = B[lane, j]
+    Dm = Am @ Bm
+    out = C.copy()
+    for lane in range(64):
+        for r in range(16):
+            out[lane, r] += Dm[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+    return out
+
+
+def tr_read(lds, addr):
+    """ds_read_b64_tr_b16: addr[64] element offsets (each lane: 4 consecutive elements) -> [64, 4]."""
+    out = np.zeros((64, 4))
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for j in range(4):  # row j of the [4][16] block comes from lanes 4j..4j+3 of the group; column i
+            src = g * 16 + 4 * j + (i >> 2)
+            out[lane, j] = lds[addr[src] + (i & 3)]
+    return out
+
+
+def run_block(q, k, v, Nq, Nk, qblk, scale, TR):
+    """One workgroup (128 query rows) of one (batch, head): q [Nq,64], k/v [Nk,64] -> {row: out[64]}."""
+    out = {}
+    n_tiles = (Nk + KT - 1) // KT
+    for wave in range(4):
+        lanes = np.arange(64)
+        ln, hi = lanes & 31, lanes >> 5
+        q_row = qblk * QB + wave * 32 + ln
+        qf = np.zeros((4, 64, 8))
+        for ks in range(4):
+            for l in range(64):
+                if q_row[l] < Nq:
+                    qf[ks, l] = q[q_row[l], 16 * ks + 8 * hi[l]: 16 * ks + 8 * hi[l] + 8]
+        oacc = np.zeros((2, 64, 16))
+        m_run = np.full(64, -np.inf)
+        l_run = np.zeros(64)
+        sl = scale * np.log2(np.e)
+        for t in range(n_tiles):
+            # ---- staging (what write_lds does for all 256 threads) ----
+            ks_lds = np.zeros(KT * K_LD)
+            vs_lds = np.zeros(KT * V_LD_TR if TR else D * V_LD_T)
+            for tid in range(256):
+                for i in range(2):
+                    idx = tid + 256 * i
+                    row, col = t * KT + (idx >> 3), (idx & 7) * 8
+                    kr = k[row, col:col + 8] if row < Nk else np.zeros(8)
+                    ks_lds[(idx >> 3) * K_LD + col: (idx >> 3) * K_LD + col + 8] = kr
+                    if TR:
+                        vr = v[row, col:col + 8] if row < Nk else np.zeros(8)
+                        vs_lds[(idx >> 3) * V_LD_TR + col: (idx >> 3) * V_LD_TR + col + 8] = vr
+                if not TR:
+                    kp, c = tid >> 3, tid & 7
+                    r0, r1 = t * KT + 2 * kp, t * KT + 2 * kp + 1
+                    a = v[r0, c * 8:c * 8 + 8] if r0 < Nk else np.zeros(8)
+                    b = v[r1, c * 8:c * 8 + 8] if r1 < Nk else np.zeros(8)
+                    for e in range(8):
+                        vs_lds[(8 * c + e) * V_LD_T + 2 * kp] = a[e]
+                        vs_lds[(8 * c + e) * V_LD_T + 2 * kp + 1] = b[e]
+            # ---- S^T = K Q^T ----
+            s = np.zeros((2, 64, 16))
+            for ks in range(4):
+                for kb in range(2):
+                    kf = np.zeros((64, 8))
+                    for l in range(64):
+                        a0 = (32 * kb + ln[l]) * K_LD + 16 * ks + 8 * hi[l]
+                        kf[l] = ks_lds[a0:a0 + 8]
+                    s[kb] = mfma_32x32x16(kf, qf[ks], s[kb])
+            if (t + 1) * KT > Nk:
+                for kb in range(2):
+                    for r in range(16):
+                        key = t * KT + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3)
+                        s[kb][key >= Nk, r] = -np.inf
+            mx = np.maximum(s[0].max(1), s[1].max(1))
+            mx = np.maximum(mx, mx[lanes ^ 32])
+            m_new = np.maximum(m_run, mx)
+            alpha = np.exp2(m_run * sl - m_new * sl)
+            m_run = m_new
+            e = np.exp2(s * sl - (m_new * sl)[None, :, None])
+            l_run = l_run * alpha + e.sum((0, 2))
+            oacc *= alpha[None, :, None]
+            for st in range(4):
+                pf = e[st >> 1][:, 8 * (st & 1): 8 * (st & 1) + 8]
+                for db in range(2):
+                    if TR:
+                        row = 16 * st + 4 * hi + ((lanes & 15) >> 2)
+                        col = 32 * db + 16 * ((lanes >> 4) & 1) + 4 * (lanes & 3)
+                        lo = tr_read(vs_lds, row * V_LD_TR + col)
+                        hi4 = tr_read(vs_lds, (row + 8) * V_LD_TR + col)
+                        vf = np.concatenate([lo, hi4], 1)
+                    else:
+                        vf = np.zeros((64, 8))
+                        for l in range(64):
+                            a0 = (32 * db + ln[l]) * V_LD_T + 16 * st + 4 * hi[l]
+                            vf[l, :4] = vs_lds[a0:a0 + 4]
+                            vf[l, 4:] = vs_lds[a0 + 8:a0 + 12]
+                    oacc[db] = mfma_32x32x16(vf, pf, oacc[db])
+        l_tot = l_run + l_run[lanes ^ 32]
+        for l in range(64):
+            if q_row[l] < Nq:
+                o = out.setdefault(int(q_row[l]), np.zeros(D))
+                for db in range(2):
+                    for g in range(4):
+                        for e_ in range(4):
+                            o[32 * db + 8 * g + 4 * hi[l] + e_] = oacc[db][l, 4 * g + e_] / l_tot[l]
+    return out
+
+
+def reference(q, k, v, scale):
+    s = (q @ k.T) * scale
+    p = np.exp(s - s.max(1, keepdims=True))
+    return (p / p.sum(1, keepdims=True)) @ v
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    for (Nq, Nk) in [(128, 128), (100, 77), (160, 200)]:
+        q, k, v = rng.standard_normal((Nq, D)), rng.standard_normal((Nk, D)), rng.standard_normal((Nk, D))
+        want = reference(q, k, v, 0.125)
+        for TR in (True, False):
+            err, rows = 0.0, 0
+            for qblk in range((Nq + QB - 1) // QB):
+                got = run_block(q, k, v, Nq, Nk, qblk, 0.125, TR)
+                for r, o in got.items():
+                    err = max(err, np.abs(o - want[r]).max())
+                    rows += 1
+            print(f"Nq={Nq} Nk={Nk} v_path={'tr' if TR else 'vt'}: rows={rows} max|err|={err:.2e}")
+            assert rows == Nq and err < 1e-12
+    print("index math OK")

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-2 GPU session 1: full -m gpu suite (new kernels, real-arch parity, cfg4), micro-benchmarks, per-rank batch table,
+# MIOpen NHWC diagnostic.  Everything lands in gpurun_out/s1/.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/s1; mkdir -p $O
+# new kernels first, in their own process (a faulting kernel must not take the rest of the suite down with it)
+( time timeout 600 python -m pytest tests/test_unet_kernels.py -q -m gpu --timeout 300 -p no:cacheprovider -s ) > $O/pytest_kernels.log 2>&1
+tail -4 $O/pytest_kernels.log
+grep -E "FAILED|Error" $O/pytest_kernels.log | head -20
+if grep -q "flash.*FAILED\|FAILED.*flash" $O/pytest_kernels.log; then export ED_DISABLE=FLASH_ATTENTION; echo "flash attention tests failed: rest of the session runs with ED_DISABLE=$ED_DISABLE"; fi
+( time timeout 1500 python -m pytest tests -q -m gpu --timeout 600 -p no:cacheprovider -s --deselect tests/test_unet_kernels.py ) > $O/pytest.log 2>&1
+tail -5 $O/pytest.log
+grep -E "FAILED|Error" $O/pytest.log | head -20
+grep -hE "flash .* path|bit-identical|small SDXL|^\{" $O/pytest_kernels.log $O/pytest.log > $O/pytest_numbers.log
+( time timeout 600 python tools/r2_probe.py attn fused unet table=20,10,6,3 ) > $O/probe.log 2>&1
+grep "^{" $O/probe.log
+( timeout 240 python tools/miopen_nhwc_diag.py nhwc ) > $O/diag_nhwc.log 2>&1
+grep -E "DIAG|ufdb|udb|FindSolution|Perf Db|PerfDb|record|Solver" $O/diag_nhwc.log | cut -c1-300 | tail -60
+( time timeout 400 python tools/r2_probe.py table=5,1 ) > $O/probe_small.log 2>&1
+grep "^{" $O/probe_small.log
