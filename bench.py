@@ -155,6 +155,54 @@ def kernel_replay(pipe, wl, T, reps=200):
     return res
 
 
+def unet_kernel_profile(pipe, wl, T):
+    """In-situ duration of every hand-written kernel INSIDE the UNet, at the workload's real launch shapes: one eager
+    (not graph-replayed) forward of the phase-A batch and one of the phase-B batch with HIP events recorded on the
+    launch stream around each ed_* launch (ops.TIMER), weighted by how often each phase runs per image.  Algorithmic
+    FLOPs / bytes per launch are declared by the wrappers (ops.TIMER.note_work).  -> {kernel: {...}}"""
+    from elasticdiffusion_official_amd import geometry, ops
+    s = pipe.vae_scale_factor
+    vc = pipe.view_config
+    V = geometry.ViewPlan(wl["H"] // s, wl["W"] // s, vc["window_size"], vc["stride"], vc["context_size"]).V
+    d = pipe.model_size
+    cfg = pipe.unet.config
+    res = {}
+    for rows, per_image in ((2 * (wl["R"] + 1) + V, T), (2 + V, T - 1)):
+        x = torch.randn(rows, 4, d, d, device=pipe.device, dtype=pipe.model_dtype)
+        txt = torch.randn(rows, 77, cfg.cross_attention_dim, device=pipe.device, dtype=pipe.model_dtype)
+        pl = None if not cfg.pooled_projection_dim else torch.randn(rows, cfg.pooled_projection_dim, device=pipe.device,
+                                                                    dtype=pipe.model_dtype)
+        t = torch.tensor(500, device=pipe.device)
+        with torch.no_grad():
+            pipe._forward_rows(x, t, txt, pl, None)  # warm (kernels loaded, fused weights built)
+            ops.TIMER.start()
+            pipe._forward_rows(x, t, txt, pl, None)
+            work = None
+            times = ops.TIMER.stop()
+            work = dict(ops.TIMER.work)
+        for name, (n, mean_us, total_ms) in times.items():
+            r = res.setdefault(name, {"launches_per_image": 0, "ms_per_image": 0.0, "flops_per_image": 0.0,
+                                      "bytes_per_image": 0.0})
+            r["launches_per_image"] += n * per_image
+            r["ms_per_image"] += total_ms * per_image
+            r["flops_per_image"] += work.get(name, [0, 0])[0] * per_image
+            r["bytes_per_image"] += work.get(name, [0, 0])[1] * per_image
+    for r in res.values():
+        sec = r["ms_per_image"] * 1e-3
+        r["mean_us"] = round(1e3 * r["ms_per_image"] / max(1, r["launches_per_image"]), 2)
+        r["tflops"] = round(r["flops_per_image"] / sec / 1e12, 1) if r["flops_per_image"] else None
+        r["gbs"] = round(r["bytes_per_image"] / sec / 1e9, 1) if r["bytes_per_image"] else None
+        r["ms_per_image"] = round(r["ms_per_image"], 2)
+    return res
+
+
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,13 +211,22 @@ def main():
     ap.add_argument("--workload", default="sdxl_1024x2048", choices=list(WORKLOADS))
     ap.add_argument("--timesteps", type=int, default=50, help="denoising steps per image (the metric is quoted at 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="bounded", choices=["bounded", "full"],
+                    help="bounded: ~10-30 s sample (default); full: SURVEY 8(d)'s cfg1 in full + two full timesteps of "
+                         "the workload (minutes of host time; run once, result kept under profiles/)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--shard-group", type=int, default=0,
-                    help="GPUs that share ONE image by row-sharding (RCCL all-gather per phase); the N/g groups work on "
-                         "different images.  0 = default: 2 when N >= 2 (89 %% modelled efficiency vs 48 %% for g = 8), "
-                         "else 1.  g = N is pure strong scaling of one image.")
+                    help="GPUs that row-shard the SAME images (RCCL all-gather per forward).  0 = all N (default): every "
+                         "rank works on every image -- view/row-parallel strong scaling.  g < N: N/g independent groups "
+                         "(replicas), each sharding its own images g ways.")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="images in flight per shard group (generate_latents_interleaved): their pending model calls are "
+                         "fused into one forward.  0 = default: max(1, g // 2); 1 = one image at a time.")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative extra measurements after the timed region")
+    ap.add_argument("--small", action="store_true",
+                    help="REHEARSAL ONLY: reduced-width architecture (models.SMALL_UNET_CONFIGS) so the whole N-rank "
+                         "control flow can be exercised in seconds; the metric name says so and the number means nothing")
     ap.add_argument("--cache-backgrounds", action="store_true",
                     help="reuse the noised pad-background frames across images of the same size (off: every image pays)")
     args = ap.parse_args()
@@ -183,10 +240,22 @@ def main():
         local_rank = 0  # rehearsal: all ranks share the only GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    g = args.shard_group or (2 if world >= 2 else 1)
+    g = args.shard_group or world
     if world % g:
         raise SystemExit(f"--shard-group {g} does not divide --gpus {world}")
-    n_groups, group_id, pg = world // g, rank // g, False
+    m = args.in_flight or max(1, g // 2)
+    n_groups, group_id = world // g, rank // g
+    groups = {}
+
+    def shard_group(size):
+        """process group of this rank's ``size``-rank shard group (False = no sharding); collective on first use"""
+        if size == 1 or world == 1:
+            return False
+        if size not in groups:
+            made = [dist.new_group(ranks=list(range(i * size, (i + 1) * size))) for i in range(world // size)]
+            groups[size] = made[rank // size]
+        return groups[size]
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ED_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N>1 logic on a 1-GPU box
@@ -194,8 +263,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        groups = [dist.new_group(ranks=list(range(i * g, (i + 1) * g))) for i in range(n_groups)]  # collective call
-        pg = groups[group_id] if g > 1 else False
 
     from elasticdiffusion_official_amd import ElasticDiffusion, models, ops
     if os.environ.get("ED_MIOPEN_FIND") == "1":
@@ -206,20 +273,36 @@ def main():
 
     wl = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    pipe = ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], model_dtype=dtype, process_group=pg,
-                            cache_backgrounds=args.cache_backgrounds)
+    inject = {}
+    if args.small:
+        inject["unet"], inject["vae"] = models.build_models(wl["sd"], device=dev, dtype=dtype, small=True)
+    pipe = ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], model_dtype=dtype, process_group=shard_group(g),
+                            cache_backgrounds=args.cache_backgrounds, **inject)
     kw = dict(height=wl["H"], width=wl["W"], num_inference_steps=args.timesteps, guidance_scale=wl["guidance"],
               resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"], rrg_init_weight=wl["rrg_w"],
-              cosine_scale=wl["cosine_scale"], repaint_sampling=True, tiled_decoder=wl["tiled"], output_type="pt")
+              cosine_scale=wl["cosine_scale"], repaint_sampling=True)
     prompt, negative = "An astronaut riding a corgi on the moon", "blurry, ugly, poorly drawn, deformed"
+    state = {"imgs": None}
 
-    def one_image(seed):
-        pipe.seed_everything(seed * n_groups + group_id)  # same seed within a shard group, different images across groups
-        imgs, _ = pipe.generate_image(prompt, negative, **kw)
-        return imgs
+    def run_images(p, seeds, in_flight):
+        """``len(seeds)`` images through pipeline ``p`` (latents + decode); all ranks of p's shard group call this with
+        the same seeds.  in_flight > 1: the interleaved driver; decode happens as each image completes."""
+        dec = p.tiled_decode if wl["tiled"] else p.decode_latents
+        if in_flight <= 1:
+            for sd_ in seeds:
+                p.seed_everything(sd_)
+                state["imgs"], _ = p.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", **kw)
+            return
+        jobs = [dict(prompts=prompt, negative_prompts=negative, seed=sd_) for sd_ in seeds]
 
-    for i in range(args.warmup):
-        one_image(1000 + i)
+        def on_done(j, z):
+            state["imgs"] = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])
+
+        p.generate_latents_interleaved(jobs, in_flight=in_flight, on_done=on_done, **kw)
+
+    def my_seeds(first, count, n_grp, gid):
+        """image seeds of this shard group: ``count`` images in total are dealt round-robin to the n_grp groups"""
+        return [first + i for i in range(count) if i % n_grp == gid]
 
     def fence():
         torch.cuda.synchronize()
@@ -227,35 +310,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(p, first, count, in_flight, n_grp, gid):
+        fence()
+        t0 = time.perf_counter()
+        run_images(p, my_seeds(first, count, n_grp, gid), in_flight)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el
+
+    # K timed images IN TOTAL (strong scaling: the work is fixed as N grows); they are dealt to the shard groups
+    n_timed = args.steps
+    run_images(pipe, my_seeds(1000, max(args.warmup, 0) * n_groups * m, n_groups, group_id), m)  # W x m images per group
     timing = (not args.no_kernel_timing)
-    fence()
     if timing:
+        fence()
         ops.TIMER.start()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        imgs = one_image(i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(pipe, 0, n_timed, m, n_groups, group_id)
     ktimes = ops.TIMER.stop() if timing else {}
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    finite = bool(torch.isfinite(imgs).all())
+    finite = bool(torch.isfinite(state["imgs"]).all()) if state["imgs"] is not None else True
     phases = pipe.phase_times()
-    # informative extra (outside the timed region, never `value`): the same image with the noised pad-background
-    # frames reused from the previous image of the same size (they depend only on geometry and the timestep schedule)
-    cached_s = None
-    if world == 1 and not args.cache_backgrounds and not args.no_extras:
-        pipe.cache_backgrounds = True
-        one_image(2000)
-        fence()
-        t1 = time.perf_counter()
-        one_image(2001)
-        fence()
-        cached_s = time.perf_counter() - t1
-        pipe.cache_backgrounds = False
-        pipe._frame_cache.clear()
+    host_ms = {k: round(1e3 * v, 1) for k, v in pipe.host_s.items()}
+    graph_stats = pipe._runner.stats()
+    rows_share = (pipe.sharder.rows_computed, pipe.sharder.rows_total)
+
+    # ---- informative extras, all OUTSIDE the timed region and never `value` ------------------------------------------
+    layouts, cached_s = {}, None
+    if not args.no_extras:
+        if world == 1 and not args.cache_backgrounds:
+            pipe.cache_backgrounds = True
+            run_images(pipe, [2000], 1)
+            cached_s = timed(pipe, 2001, 1, 1, 1, 0)
+            pipe.cache_backgrounds = False
+            pipe._frame_cache.clear()
+        if world == 1 and m == 1:
+            run_images(pipe, [3000, 3001], 2)  # capture the fused-batch graph shapes
+            layouts["1gpu_two_images_in_flight"] = dict(images=2, images_per_s=round(2 / timed(pipe, 3002, 2, 2, 1, 0), 5))
+        if world > 1:
+            # the same N GPUs in the other layouts, so that a scaling record cannot pass one off as another
+            alts = []
+            if not (g == world and m == 1):
+                alts.append(("view_parallel_one_image", world, 1))
+            if world >= 4 and not (g == 2 and m == 1):
+                alts.append(("replica_groups_2way", 2, 1))
+            for name, gg, mm in alts:
+                p2 = pipe if gg == g else ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], unet=pipe.unet,
+                                                           vae=pipe.vae, process_group=shard_group(gg),
+                                                           cache_backgrounds=args.cache_backgrounds)
+                ng, gid = world // gg, rank // gg
+                cnt = ng * mm
+                run_images(p2, my_seeds(4000, cnt, ng, gid), mm)  # warm (graph capture of this layout's shapes)
+                layouts[name] = dict(shard_group=gg, in_flight=mm, images=cnt,
+                                     images_per_s=round(cnt / timed(p2, 4100, cnt, mm, ng, gid), 5))
 
     if rank == 0:
         fam = models.family(wl["sd"])
@@ -267,12 +376,11 @@ def main():
         V = geometry.ViewPlan(Hl, Wl, vc["window_size"], vc["stride"], vc["context_size"]).V
         T, R = args.timesteps, wl["R"]
         fs = forward_samples(T, R, V)
-        flops_sample = unet_flops_per_sample(fam, dtype)
-        img_per_s = n_groups * args.steps / elapsed
-        sec_per_img = elapsed / args.steps            # latency of one image inside its shard group
-        e2e_tf = fs * flops_sample / sec_per_img / 1e12 / g
-        # per-view UNet ms: whole-image wall time / forward-samples is an upper bound that includes everything else
-        per_view_ms = 1e3 * sec_per_img * g / fs
+        flops_sample = 0.0 if args.small else unet_flops_per_sample(fam, dtype)
+        img_per_s = n_timed / elapsed
+        sec_per_img = elapsed / n_timed               # wall time per image of the whole job (all N GPUs)
+        e2e_tf = fs * flops_sample / sec_per_img / 1e12 / world
+        per_view_ms = 1e3 * sec_per_img * world / fs  # GPU-ms per forward-sample incl. everything else (upper bound)
         geo = dict(B=1, C=4, Hl=Hl, Wl=Wl, h=h, w=w, d=pipe.model_size, K=R + 1, V=V, n_sub=1000 // T, mb=2)
         kern = {}
         replay = kernel_replay(pipe, wl, T) if timing else {}
@@ -284,56 +392,84 @@ def main():
             kern[name] = dict(us_per_launch=round(us, 2), alg_bytes=int(ab), gbs=round(ab / (us * 1e-6) / 1e9, 1),
                               launches_in_timed_region=n, in_situ_us=None if in_situ is None else round(in_situ, 2),
                               est_total_ms=round(n * us * 1e-3, 3))
+        unet_k = unet_kernel_profile(pipe, wl, T) if timing and pipe.model_dtype != torch.float32 else {}
         roof = None
-        if kern:
-            dom = max(kern, key=lambda k: kern[k]["est_total_ms"])
-            a = kern[dom]["gbs"]
-            traffic = None
-            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_glue_pmc.json")))["kernels"]
-                if args.workload == "sdxl_1024x2048" and T == 50 and dom in pmc:
-                    traffic = pmc[dom]["hbm_bytes_corrected"]
-            except (OSError, KeyError, ValueError):
-                pass
-            roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/r1_glue_pmc.json (rocprofv3 --pmc, offline)",
-                    "algorithmic_bytes_per_launch": kern[dom]["alg_bytes"],
-                    "us_per_launch": kern[dom]["us_per_launch"],
-                    "note": "hand-written glue kernel with the largest total time in the timed region; duration = HIP "
-                            "events around 200 back-to-back launches at the workload's shapes; tensors are <= 11 MiB "
-                            "(L2/MALL resident, launch-latency bound); the end-to-end MFMA figure is roofline_e2e"}
+        if unet_k:
+            # the dominant hand-written kernel BY GPU TIME, whatever its bound
+            dom = max(unet_k, key=lambda k: unet_k[k]["ms_per_image"])
+            kd = unet_k[dom]
+            mfma = bool(kd["flops_per_image"])
+            ach = kd["tflops"] if mfma else kd["gbs"]
+            peak = MFMA_BF16_PEAK_TF if mfma else HBM_PEAK_GBS
+            pmc = (load_profile_json("r2_unet_pmc.json") or {}).get("kernels", {}).get(dom)
+            traffic = pmc.get("hbm_bytes_per_launch_mean") if (pmc and args.workload == "sdxl_1024x2048" and T == 50) else None
+            roof = {"kernel": dom, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/r2_unet_pmc.json (rocprofv3 --pmc FETCH_SIZE / "
+                                                                   "WRITE_SIZE passes, offline, mean bytes per launch)",
+                    "algorithmic_flops_per_launch": round(kd["flops_per_image"] / kd["launches_per_image"]),
+                    "algorithmic_bytes_per_launch": round(kd["bytes_per_image"] / kd["launches_per_image"]),
+                    "us_per_launch": kd["mean_us"], "launches_per_image": kd["launches_per_image"],
+                    "gpu_ms_per_image": kd["ms_per_image"],
+                    "share_of_image_time": round(kd["ms_per_image"] / (1e3 * sec_per_img * world), 4),
+                    "note": "dominant hand-written kernel by GPU time; durations = HIP events on the launch stream around "
+                            "every launch of one eager forward of each phase batch at the workload's shapes (inside a "
+                            "hipGraph replay the launches cannot be bracketed), means weighted by launches per image; "
+                            "profiles/ holds the rocprofv3 --kernel-trace --stats summary of this command"}
         out = {
-            "metric": "images/sec at 50 steps (SDXL 2048x1024)" if args.workload == "sdxl_1024x2048" and T == 50
+            "metric": "REHEARSAL (reduced-width architecture): not a measurement" if args.small else
+                      "images/sec at 50 steps (SDXL 2048x1024)" if args.workload == "sdxl_1024x2048" and T == 50
                       else f"images/sec at {T} steps ({args.workload})",
             "value": round(img_per_s, 5), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * sec_per_img, 2), "higher_is_better": True,
-            "scaling": "strong" if n_groups == 1 else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": args.workload, "height": wl["H"], "width": wl["W"], "denoising_steps": T,
                        "view_batch_size": wl["vbs"], "resampling_steps": R, "views": V, "prompts_per_image": 1,
-                       "unet_forward_samples_per_image": fs, "parallelism": f"{n_groups} image group(s) x {g}-way row shard (RCCL all-gather per phase)",
+                       "unet_forward_samples_per_image": fs,
+                       "parallelism": (f"{n_groups} shard group(s) x {g}-way row shard (RCCL all-gather per forward), "
+                                       f"{m} image(s) in flight per group; {args.steps} images in total whatever N"),
+                       "shard_group": g, "images_in_flight": m,
                        "background_cache": bool(args.cache_backgrounds),
                        "weights": "random-init SDXL architecture (2.567 B params), seed 0", "vae_dtype": "fp32"},
             "images_per_min": round(60 * img_per_s, 3),
             "per_view_unet_ms": round(per_view_ms, 3),
             "finite_output": finite,
+            "graphs": graph_stats,
+            "rows_computed_over_rows_total_rank0": list(rows_share),
+            "layouts": layouts,
             "extras": {"images_per_s_with_background_cache": None if cached_s is None else round(1.0 / cached_s, 5),
-                       "note": "optional cache_backgrounds=True mode, measured after the timed region; not the headline"},
+                       "note": "optional modes measured after the timed region; never the headline"},
             "phase_ms_last_image": {k: round(v, 1) for k, v in phases.items()},
-            "host_ms_last_image": {k: round(1e3 * v, 1) for k, v in pipe.host_s.items()},
+            "host_ms_last_image": host_ms,
             "roofline": roof,
             "roofline_e2e": {"bound": "mfma", "achieved": round(e2e_tf, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                              "frac": round(e2e_tf / MFMA_BF16_PEAK_TF, 4),
                              "flops_per_forward_sample": flops_sample, "forward_samples": fs,
                              "note": "UNet FLOPs only (VAE / glue excluded from the numerator), per GPU"},
+            "unet_kernels": unet_k,
             "glue_kernels": kern,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pipe, wl, T, fs, V)
+        if not args.no_cpu_baseline and world == 1 and not args.small:
+            out["cpu_baseline"] = cpu_baseline(pipe, wl, T, fs, V, args.cpu_baseline)
+            out["parity_bf16_rel_l2"] = parity_leg(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_leg(dev):
+    """Part of the CPU-baseline leg (the only place bench.py may touch oracle/): the repo's real reduced-width SDXL
+    modules through the product loop in bf16 on the GPU vs the fp32 oracle on the host cores, cfg3 geometry, 2 steps
+    (tests/realarch.py).  -> per-timestep relative L2 of the latent (fp32 product run alongside as the control)."""
+    from tests import realarch
+    t0 = time.perf_counter()
+    rep = realarch.drift_report("cfg3_xl_1024x2048", device=str(dev), with_fp32=True, with_batching=False)
+    return {"case": "reduced-width SDXL architecture (tests/realarch.py), 1024x2048, 2 timesteps, R=2, random init",
+            "bf16_vs_fp32_oracle": [float(f"{v:.3e}") for v in rep["bf16"]],
+            "fp32_vs_fp32_oracle": [float(f"{v:.3e}") for v in rep["fp32"]],
+            "rng_end_state_equal": bool(rep["bf16_rng_tail_equal"] and rep["fp32_rng_tail_equal"]),
+            "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def pick_host_threads():
@@ -361,22 +497,74 @@ def pick_host_threads():
     return best[1], best[0]
 
 
-def cpu_baseline(pipe, wl, T, fs, V):
-    """The oracle (kind "port": op-for-op CPU restatement of the reference, fixture-pinned) timed on the host cores on
-    a BOUNDED sample of the same workload: ONE fp32 UNet forward-sample at the model size on the CPU + the oracle glue
-    of ONE full timestep (zero-cost UNet), extrapolated to the image: fs * t_sample + T * t_glue (decode excluded).
-    Reported baseline, not the optimisation target."""
-    import copy
+def _oracle_for(pipe, wl, unet, vae):
     from oracle.ddim import DDIMOracle
     from oracle.elastic_oracle import ElasticOracle
+    un, pun = pipe.get_text_embeds([""])
+    un, pun = un.cpu().float(), pun.cpu().float()
+    xl = wl["sd"].startswith("XL")
+    return ElasticOracle(unet, vae, DDIMOracle(), lambda _: (un, pun), sd_version=wl["sd"], view_batch_size=wl["vbs"],
+                         pooled_dim=pun.shape[-1] if xl else None)
+
+
+def cpu_baseline(pipe, wl, T, fs, V, mode="bounded"):
+    """The oracle (kind "port": op-for-op CPU restatement of the reference, fixture-pinned) with this repo's own fp32
+    UNet / VAE modules, timed on the host cores.  Reported baseline, not the optimisation target.
+
+    bounded (default, ~10-30 s of host work): ONE fp32 UNet forward-sample at the model size + the oracle glue of ONE
+      full timestep (zero-cost UNet, so only the reference's tensor glue is timed) + ONE real pad-strip VAE encode + the
+      VAE decode at a quarter of the image area (scaled x4), extrapolated:
+          s/image = fs * t_sample + T * t_glue + n_strips * t_strip + t_decode
+    full (minutes): cfg1 (SD1.5 512x512, 10 steps, R=0) end to end, and TWO full timesteps of the workload
+      (all forward-samples, real strips) through the oracle, extrapolated x T/2, plus the full-size decode."""
+    import copy
+    from elasticdiffusion_official_amd import models as M
     cores, gflops = pick_host_threads()
     torch.set_num_threads(cores)
+    fam = M.family(wl["sd"])
     unet32 = copy.deepcopy(pipe.unet).to("cpu", torch.float32)
+    vae32 = copy.deepcopy(pipe.vae).to("cpu", torch.float32)
     cfg = unet32.config
     S = cfg.sample_size
-    flops_full = unet_flops_per_sample(__import__("elasticdiffusion_official_amd").models.family(wl["sd"]), torch.float32)
-    # keep the sample bounded (~10-30 s): if a full-size forward is projected to take longer than 45 s on these
-    # cores, time it at half the spatial size and scale by the FLOP ratio (stated in "sample")
+    s8 = pipe.vae_scale_factor
+    Hl, Wl = wl["H"] // s8, wl["W"] // s8
+    okw = dict(height=wl["H"], width=wl["W"], num_inference_steps=T, guidance_scale=wl["guidance"],
+               resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"], rrg_init_weight=wl["rrg_w"],
+               cosine_scale=wl["cosine_scale"])
+    if mode == "full":
+        # (a) cfg1 end to end with the real SD1.5 architecture in fp32
+        u15, v15 = M.build_models("1.5", device="cpu", dtype=torch.float32)
+        from oracle.ddim import DDIMOracle
+        from oracle.elastic_oracle import ElasticOracle
+        e15 = torch.randn(1, 77, 768)
+        o1 = ElasticOracle(u15, v15, DDIMOracle(), lambda _: (e15, e15), sd_version="1.5", view_batch_size=1)
+        o1.seed_everything(0)
+        t0 = time.perf_counter()
+        z1 = o1.generate_latent("p", "", height=512, width=512, num_inference_steps=10, guidance_scale=10.0,
+                                resampling_steps=0, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000, cosine_scale=10.0)
+        o1.decode_latents(z1)
+        t_cfg1 = time.perf_counter() - t0
+        del u15, v15, o1
+        # (b) two full timesteps of the workload, everything real
+        orc = _oracle_for(pipe, wl, unet32, vae32)
+        orc.seed_everything(0)
+        t0 = time.perf_counter()
+        z = orc.generate_latent("p", "", progress=lambda ts: list(ts)[:2], **okw)
+        t_two = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.decode_latents(z)
+        t_dec = time.perf_counter() - t0
+        sec_img = t_two * T / 2 + t_dec
+        return {"value": round(1.0 / sec_img, 8), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"full mode: 2 of {T} timesteps of the workload through the oracle with the real fp32 UNet/VAE "
+                          f"on {cores} threads ({t_two:.0f} s incl. real pad strips) x {T}/2 + full-size VAE decode "
+                          f"({t_dec:.0f} s) = {sec_img:.0f} s/image; cfg1 (SD1.5 512x512, 10 steps, R=0, real "
+                          f"architecture, decode included) end to end: {t_cfg1:.1f} s",
+                "cfg1_end_to_end_s": round(t_cfg1, 2), "two_timesteps_s": round(t_two, 1), "decode_s": round(t_dec, 1)}
+
+    flops_full = unet_flops_per_sample(fam, torch.float32)
+    # keep the sample bounded: if a full-size forward is projected to take longer than 45 s on these cores, time it at
+    # half the spatial size and scale by the FLOP ratio (stated in "sample")
     S_run = S if flops_full / (gflops * 1e9 * 0.5) < 45 else S // 2
     x = torch.randn(1, 4, S_run, S_run)
     e = torch.randn(1, 77, cfg.cross_attention_dim)
@@ -391,8 +579,7 @@ def cpu_baseline(pipe, wl, T, fs, V):
     if S_run != S:
         from torch.utils.flop_counter import FlopCounterMode
         with torch.device("meta"), FlopCounterMode(display=False) as fc:
-            m = type(unet32)(**__import__("elasticdiffusion_official_amd").models.UNET_CONFIGS[
-                __import__("elasticdiffusion_official_amd").models.family(wl["sd"])])
+            m = type(unet32)(**M.UNET_CONFIGS[fam])
             m(torch.empty(1, 4, S_run, S_run), torch.empty((), dtype=torch.int64),
               encoder_hidden_states=torch.empty(1, 77, cfg.cross_attention_dim),
               added_cond_kwargs=None if kw is None else {"text_embeds": torch.empty(1, cfg.pooled_projection_dim), "time_ids": torch.empty(1, 6)})
@@ -410,38 +597,48 @@ def cpu_baseline(pipe, wl, T, fs, V):
         def forward(self, x, t, **k):
             return {"sample": x * 0.5}
 
-    class TinyVAE(torch.nn.Module):  # the pad-strip path calls vae.encode; give it an 8x8 average so it stays bounded
+    class TinyVAE(torch.nn.Module):  # glue-only leg: the strips' VAE cost is timed separately on the real encoder
         def __init__(self, vae):
             super().__init__()
             self.config = vae.config
 
         def encode(self, img):
             m = torch.nn.functional.avg_pool2d(img, 8).mean(1, keepdim=True).repeat(1, 8, 1, 1)
-            from elasticdiffusion_official_amd.models import DiagonalGaussian
-            return type("E", (), {"latent_dist": DiagonalGaussian(m)})()
+            return type("E", (), {"latent_dist": M.DiagonalGaussian(m)})()
 
-    emb = {"n": 0}
-    un, pun = pipe.get_text_embeds([""])
-    un, pun = un.cpu().float(), pun.cpu().float()
-
-    def embeds(_):
-        return un, pun
-
-    orc = ElasticOracle(ZeroCostUNet(), TinyVAE(pipe.vae), DDIMOracle(), embeds, sd_version=wl["sd"],
-                        view_batch_size=wl["vbs"])
+    orc = _oracle_for(pipe, wl, ZeroCostUNet(), TinyVAE(pipe.vae))
+    orc.pooled_dim = None
     orc.seed_everything(0)
     t0 = time.perf_counter()
-    orc.generate_latent("p", "", height=wl["H"], width=wl["W"], num_inference_steps=T, guidance_scale=wl["guidance"],
-                        resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"],
-                        rrg_init_weight=wl["rrg_w"], cosine_scale=wl["cosine_scale"],
-                        progress=lambda ts: list(ts)[:1])
+    orc.generate_latent("p", "", progress=lambda ts: list(ts)[:1], **okw)
     t_glue = time.perf_counter() - t0
-    sec_img = fs * t_sample + T * t_glue
+    # one real pad-strip encode (ED:350) and the reference's strip count per image (2 per padded global call)
+    from elasticdiffusion_official_amd import geometry
+    h, w = pipe.get_downsample_size(wl["H"], wl["W"])
+    gpad = geometry.PadPlan(h, w, pipe.model_size)
+    n_strips, t_strip = 0, 0.0
+    if gpad.strips:
+        _, _, Hs, Ws, _, _ = gpad.strips[0]
+        img = torch.rand(1, 3, 1, 1).expand(1, 3, Hs * s8, Ws * s8).contiguous()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            vae32.encode(img).latent_dist.sample()
+            t_strip = time.perf_counter() - t0
+        calls = (T - 1) * ((wl["R"] + 1) + 1) + (wl["R"] + 1)  # global UNet calls per image (phase A + RePaint)
+        n_strips = calls * len(gpad.strips)
+    with torch.no_grad():
+        zq = torch.randn(1, 4, Hl // 2, Wl // 2)
+        t0 = time.perf_counter()
+        vae32.decode(zq / vae32.config.scaling_factor)
+        t_dec = 4.0 * (time.perf_counter() - t0)
+    sec_img = fs * t_sample + T * t_glue + n_strips * t_strip + t_dec
     return {"value": round(1.0 / sec_img, 8), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {fs} fp32 UNet forward-samples ({t_sample:.2f} s{scaled}) + oracle glue of 1 of {T} timesteps "
-                      f"({t_glue:.2f} s, zero-cost UNet), extrapolated: {fs}*t_sample + {T}*t_glue = {sec_img:.0f} s/image; "
-                      "the reference's 898 pad-strip VAE encodes and the VAE decode are excluded (favours the CPU)",
-            "t_forward_sample_s": round(t_sample, 3), "t_glue_step_s": round(t_glue, 3)}
+            "sample": f"bounded: 1 of {fs} fp32 UNet forward-samples ({t_sample:.2f} s{scaled}) + oracle glue of 1 of {T} "
+                      f"timesteps ({t_glue:.2f} s, zero-cost UNet) + 1 of {n_strips} pad-strip VAE encodes "
+                      f"({t_strip:.2f} s, real fp32 encoder) + VAE decode at 1/4 area x4 ({t_dec:.1f} s); extrapolated: "
+                      f"{fs}*t_sample + {T}*t_glue + {n_strips}*t_strip + t_decode = {sec_img:.0f} s/image on {cores} threads",
+            "t_forward_sample_s": round(t_sample, 3), "t_glue_step_s": round(t_glue, 3),
+            "t_strip_encode_s": round(t_strip, 3), "t_decode_s": round(t_dec, 2)}
 
 
 if __name__ == "__main__":

@@ -45,11 +45,13 @@ class GraphedForward:
         self.epoch += 1
 
     @staticmethod
-    def _key(shape, dtype, cond):
-        return (tuple(shape), dtype, None if cond is None else (tuple(cond.shape), cond.dtype))
+    def _key(shape, dtype, cond, t_shape=()):
+        """One graph per (rows shape, dtype, condition rows, timestep shape): the timestep is a 0-d tensor when all
+        rows share it and a per-row vector when the rows of several images in flight were fused into one batch."""
+        return (tuple(shape), dtype, None if cond is None else (tuple(cond.shape), cond.dtype), tuple(t_shape))
 
     def input_rows(self, shape, dtype, device, cond=None):
-        """The static model-input tensor for this batch shape (allocated on first request)."""
+        """The static model-input tensor for this batch shape (allocated on first request; 0-d timestep)."""
         if not self.enabled:
             return torch.empty(shape, dtype=dtype, device=device)
         key = self._key(shape, dtype, cond)
@@ -88,10 +90,12 @@ class GraphedForward:
                 gc.enable()
         ent["graph"] = graph
 
-    def __call__(self, x, t, text=None, pooled=None, cond=None):
+    def __call__(self, x, t, text=None, pooled=None, cond=None, fresh_side=False):
+        """``fresh_side``: the text / pooled / condition rows differ from call to call (fused batches of several images
+        in flight), so they are copied into the graph's static buffers on every replay, not once per image."""
         if not self.enabled:
             return self.fwd(x, t, text, pooled, cond)
-        key = self._key(x.shape, x.dtype, cond)
+        key = self._key(x.shape, x.dtype, cond, t.shape)
         ent = self.entries.get(key)
         if ent is None:
             ent = {"x": torch.empty_like(x), "graph": None, "epoch": -1, "eager": False}
@@ -111,7 +115,7 @@ class GraphedForward:
                 return self.fwd(x, t, text, pooled, cond)
             ent["epoch"] = self.epoch
         ent["t"].copy_(t)
-        if ent["epoch"] != self.epoch:
+        if fresh_side or ent["epoch"] != self.epoch:
             for name, src in (("text", text), ("pooled", pooled), ("cond", cond)):
                 if src is not None:
                     ent[name].copy_(src)

@@ -30,12 +30,14 @@ class KernelTimer:
     def __init__(self):
         self.enabled = False
         self.events = {}
+        self.work = {}
 
     def start(self):
-        self.events, self.enabled = {}, True
+        self.events, self.work, self.enabled = {}, {}, True
 
     def stop(self):
-        """-> {kernel: (launches, mean_us, total_ms)}; synchronises."""
+        """-> {kernel: (launches, mean_us, total_ms)}; synchronises.  ``self.work[kernel]`` = [flops, bytes] summed over
+        the timed launches (ALGORITHMIC work each wrapper declared via ``note_work``)."""
         self.enabled = False
         torch.cuda.synchronize()
         out = {}
@@ -43,6 +45,12 @@ class KernelTimer:
             ms = [a.elapsed_time(b) for a, b in evs]
             out[name] = (len(ms), 1e3 * sum(ms) / len(ms), sum(ms))
         return out
+
+    def note_work(self, name, flops=0.0, nbytes=0.0):
+        if self.enabled and not torch.cuda.is_current_stream_capturing():
+            w = self.work.setdefault(name, [0.0, 0.0])
+            w[0] += flops
+            w[1] += nbytes
 
 
 TIMER = KernelTimer()
@@ -252,6 +260,7 @@ def geglu(x2, inner):
     """x2 [..., 2*inner] (16-bit, contiguous) -> [..., inner] = x2[..., :inner] * gelu(x2[..., inner:])."""
     assert x2.shape[-1] == 2 * inner
     out = torch.empty(x2.shape[:-1] + (inner,), dtype=x2.dtype, device=x2.device)
+    TIMER.note_work("ed_geglu", nbytes=1.5 * x2.numel() * x2.element_size())  # read 2I, write I
     _call("ed_geglu", _dev(x2, None, "x2"), _dev(out, None, "out"), _code(x2, "x2"), x2.numel() // (2 * inner), inner,
           _stream())
     return out
@@ -264,6 +273,7 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False, chan_bias=N
     if chan_bias is not None:
         assert tuple(chan_bias.shape) == (N, C)
     out = torch.empty((N, H * W, C) if tokens else (N, C, H, W), dtype=x.dtype, device=x.device)
+    TIMER.note_work("ed_groupnorm", nbytes=3.0 * x.numel() * x.element_size())  # statistics pass + apply pass + write
     _call("ed_groupnorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
           _opt(chan_bias, x.dtype, "chan_bias"), _dev(out, None, "out"), _code(x, "x"), N, C, H * W, groups, float(eps),
           int(silu), int(tokens), _stream())
@@ -289,6 +299,7 @@ def layernorm(x, gamma, beta, eps):
     """x [..., D] contiguous 16-bit -> LayerNorm over D."""
     D = x.shape[-1]
     out = torch.empty_like(x)
+    TIMER.note_work("ed_layernorm", nbytes=2.0 * x.numel() * x.element_size())
     _call("ed_layernorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
           _dev(out, None, "out"), _code(x, "x"), x.numel() // D, D, float(eps), _stream())
     return out
@@ -299,6 +310,7 @@ def add_layernorm(a, b, gamma, beta, eps):
     D = a.shape[-1]
     assert a.shape == b.shape and a.dtype == b.dtype
     s, out = torch.empty_like(a), torch.empty_like(a)
+    TIMER.note_work("ed_add_layernorm", nbytes=4.0 * a.numel() * a.element_size())
     _call("ed_add_layernorm", _dev(a, None, "a"), _dev(b, a.dtype, "b"), _dev(gamma, a.dtype, "gamma"),
           _dev(beta, a.dtype, "beta"), _dev(s, None, "sum"), _dev(out, None, "out"), _code(a, "a"), a.numel() // D, D,
           float(eps), _stream())
@@ -310,6 +322,7 @@ def tokens_add_nchw(x, tokens):
     N, C, H, W = x.shape
     assert tuple(tokens.shape) == (N, H * W, C) and tokens.dtype == x.dtype
     out = torch.empty_like(x)
+    TIMER.note_work("ed_tokens_add_nchw", nbytes=3.0 * x.numel() * x.element_size())
     _call("ed_tokens_add_nchw", _dev(x, None, "x"), _dev(tokens, None, "tokens"), _dev(out, None, "out"), _code(x, "x"),
           N, C, H * W, _stream())
     return out
@@ -334,6 +347,9 @@ def flash_attention(q, k, v, heads, v_path=None):
         elif _LAUNCH["device"] != t.device:
             _reject(f"flash_attention: {name} lives on {t.device}, q on {_LAUNCH['device']}")
     out = torch.empty(B, Nq, HD, dtype=q.dtype, device=q.device)
+    # algorithmic work: QK^T and PV contractions (4 B H Nq Nk 64 flop); q, k, v read once, out written once
+    TIMER.note_work("ed_flash_attention", flops=4.0 * B * heads * Nq * Nk * 64,
+                    nbytes=2.0 * q.element_size() * HD * B * (Nq + Nk))
     _call("ed_flash_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _code(q, "q"), B, heads, Nq, Nk,
           64, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
           0.125, FLASH_V_PATH if v_path is None else int(v_path), _stream())

@@ -71,6 +71,40 @@ class _Plan:
     """Per-call geometry: host plans (geometry.py) + their int32 device tables + the pick sampler."""
 
 
+class _ModelCall:
+    """One request of a denoising program to the model boundary: ``rows`` [n,C,d,d] in the model dtype at timestep
+    ``t`` (0-d device tensor) with per-row text / pooled / ControlNet-condition rows.  Programs are generators that
+    yield these and receive the model output rows (see ``_phase_steps``): the driver decides whether a call runs on its
+    own (one image in flight) or fused with the calls of other images (``generate_latents_interleaved``)."""
+    __slots__ = ("rows", "t", "text", "pooled", "cond", "direct")
+
+    def __init__(self, rows, t, text, pooled, cond=None, direct=False):
+        self.rows, self.t, self.text, self.pooled, self.cond, self.direct = rows, t, text, pooled, cond, direct
+
+
+class _HostRng:
+    """The host generator state of ONE image in flight (torch CPU generator + numpy MT19937).  The reference runs
+    images one after the other on the global generators; with several images interleaved, each program must see
+    exactly the stream it would have seen alone, so the globals are swapped in and out around every turn."""
+
+    def __init__(self, seed):
+        outer = (torch.get_rng_state(), np.random.get_state())
+        host_rng.seed_everything(seed)
+        self.state = (torch.get_rng_state(), np.random.get_state())
+        torch.set_rng_state(outer[0])
+        np.random.set_state(outer[1])
+
+    def __enter__(self):
+        self.outer = (torch.get_rng_state(), np.random.get_state())
+        torch.set_rng_state(self.state[0])
+        np.random.set_state(self.state[1])
+
+    def __exit__(self, *exc):
+        self.state = (torch.get_rng_state(), np.random.get_state())
+        torch.set_rng_state(self.outer[0])
+        np.random.set_state(self.outer[1])
+
+
 class _Stager:
     """Pinned host staging ring: host RNG results are written into pinned memory and uploaded with an async copy;
     a slot is reused only after its copy event has completed, so the host may run ahead of the GPU."""
@@ -291,7 +325,8 @@ class ElasticDiffusion(nn.Module):
                     outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
                 return torch.cat(outs)
 
-            strips = self.sharder.run(encode, torch.arange(T, device=self.device), None, None, None)
+            strips = self.sharder.run(encode, torch.arange(T, device=self.device), None, None, None,
+                                      out_like=((C, Hs, Ws), torch.float32))
             frames[:, :, y0:y0 + Hs, x0:x0 + Ws] = strips
         if self.cache_backgrounds:
             self._frame_cache[key] = frames
@@ -317,16 +352,22 @@ class ElasticDiffusion(nn.Module):
             kw["down_block_additional_residuals"], kw["mid_block_additional_residual"] = down, mid
         return self.unet(x, t_dev, encoder_hidden_states=txt, **kw)["sample"].contiguous()
 
-    def _run_model(self, x_rows, t_dev, text, pooled, cond_rows=None):
-        """Rows are sharded across ranks (sharding.py); each rank's share runs as one (graph-replayed) forward."""
-        return self.sharder.run(lambda x, txt, pl, cond: self._runner(x, t_dev, txt, pl, cond),
-                                x_rows, text, pooled, cond_rows)
+    def _run_model(self, x_rows, t_dev, text, pooled, cond_rows=None, fresh_side=False):
+        """Rows are sharded across ranks (sharding.py); each rank's share runs as one (graph-replayed) forward.
+        ``t_dev``: 0-d timestep shared by all rows, or one timestep per row (fused batches of several images)."""
+        if t_dev.dim() == 0:
+            return self.sharder.run(lambda x, txt, pl, cond: self._runner(x, t_dev, txt, pl, cond, fresh_side),
+                                    x_rows, text, pooled, cond_rows)
+        return self.sharder.run(lambda x, txt, pl, cond, t: self._runner(x, t, txt, pl, cond, fresh_side),
+                                x_rows, text, pooled, cond_rows, t_dev)
 
     # ---- one estimation phase (ED:1016-1035 or ED:1043-1056) ---------------------------------------
-    def _phase(self, P, x, ti, K, g, drop_p, emb, cond=None):
+    def _phase_steps(self, P, x, ti, K, g, drop_p, emb, cond=None, direct=True):
+        """Generator: pre-model glue -> ``yield _ModelCall`` (receives the model output rows) -> post-model glue;
+        returns (prev, x0, info).  ``direct``: assemble straight into the hipGraph's static input (one image in flight,
+        one rank); otherwise into a scratch batch the driver concatenates / the sharder slices."""
         B, C = x.shape[:2]
         dev, mdt = self.device, self.model_dtype
-        t = self._timesteps[ti]
         n_g, n_v = 2 * K * B, P.views.V * B
         # host draws first (they never wait for the GPU)
         h0 = time.perf_counter()
@@ -343,12 +384,11 @@ class ElasticDiffusion(nn.Module):
         gframe = None if self._gframes is None else self._gframes[ti]
         vframe = None if self._vframes is None else self._vframes[ti]
         low = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
+        direct = direct and P.one_batch and self.sharder.world_size == 1
         if P.one_batch:
             shape = (n_g + n_v, C, P.gpad.PH, P.gpad.PW)
-            # single rank: assemble straight into the graph's static input; sharded: into a scratch batch that
-            # the sharder slices per rank
-            rows = (self._runner.input_rows(shape, mdt, dev, None if cond is None else cond[K])
-                    if self.sharder.world_size == 1 else torch.empty(shape, device=dev, dtype=mdt))
+            rows = (self._runner.input_rows(shape, mdt, dev, None if cond is None else cond[K]) if direct
+                    else torch.empty(shape, device=dev, dtype=mdt))
             g_rows, v_rows = rows[:n_g], rows[n_g:]
         else:
             g_rows = torch.empty(n_g, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
@@ -357,15 +397,17 @@ class ElasticDiffusion(nn.Module):
         ops.gather_views(x, v_rows, P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, vframe)
         text, pooled = emb[K]
         t_dev = self._t_dev[ti]
+        self.host_s["phase_total"] += time.perf_counter() - h0
         if P.one_batch:
-            out = self._run_model(rows, t_dev, text, pooled, None if cond is None else cond[K])
+            out = yield _ModelCall(rows, t_dev, text, pooled, None if cond is None else cond[K], direct)
             g_out, v_out = out[:n_g], out[n_g:]
         else:
-            g_out = self._run_model(g_rows, t_dev, text[:n_g].contiguous(), pooled[:n_g].contiguous(),
-                                    None if cond is None else cond[K][0])
-            v_out = self._run_model(v_rows, t_dev, text[n_g:].contiguous(), pooled[n_g:].contiguous(),
-                                    None if cond is None else cond[K][1])
-            g_out, v_out = g_out.clone(), v_out  # two calls may share one graph output buffer when shapes coincide
+            g_out = yield _ModelCall(g_rows, t_dev, text[:n_g].contiguous(), pooled[:n_g].contiguous(),
+                                     None if cond is None else cond[K][0])
+            g_out = g_out.clone()  # the two calls may share one graph output buffer when their shapes coincide
+            v_out = yield _ModelCall(v_rows, t_dev, text[n_g:].contiguous(), pooled[n_g:].contiguous(),
+                                     None if cond is None else cond[K][1])
+        h0 = time.perf_counter()
         dirs = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
         uncond_last = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
         ops.unpad_direction(g_out, dirs, uncond_last, P.gpad.top, P.gpad.left)
@@ -380,6 +422,15 @@ class ElasticDiffusion(nn.Module):
         info = {"low_latent": low[K - 1], "uncond_score": uncond_last, "low_direction": low_dir,
                 "direction": direction, "local": local, "init_low": low[0]}
         return prev, x0, info
+
+    def _drive(self, program):
+        """Run one program alone: every model call is its own (graph-replayed, row-sharded) forward."""
+        try:
+            call = next(program)
+            while True:
+                call = program.send(self._run_model(call.rows, call.t, call.text, call.pooled, call.cond))
+        except StopIteration as stop:
+            return stop.value
 
     def _undo(self, x, ti_next):
         """ED:692-704; noise drawn on the host generator in the reference's order, staged through pinned memory."""
@@ -433,6 +484,92 @@ class ElasticDiffusion(nn.Module):
         return out
 
     # ---- the loop (ED:953-1078) --------------------------------------------------------------------
+    def _setup_run(self, height, width, num_inference_steps, guidance_scale, resampling_steps, new_p, rrg_stop_t,
+                   rrg_init_weight, rrg_scherduler_cls, cosine_scale, repaint_sampling, controlnet_conditioning_scale):
+        """Everything of one ``generate_image`` call that does not depend on the prompt, the seed or the condition
+        image: geometry tables, schedules, the noised pad-background frames.  Shared by all images in flight."""
+        self._mark("start")
+        self.host_s = {"picks": 0.0, "phase_total": 0.0, "noise": 0.0, "stager_wait": 0.0}
+        self._stager.waited = 0.0
+        S = _Plan()
+        S.P = P = self._plan(height, width)
+        self.default_size = (4 * height, 4 * width)  # ED:969
+        n_rrg = num_inference_steps - int(num_inference_steps * rrg_stop_t)
+        if rrg_scherduler_cls is CosineScheduler or getattr(rrg_scherduler_cls, "__name__", "") == "CosineScheduler":
+            S.rrg = rrg_scherduler_cls(steps=n_rrg, cosine_scale=cosine_scale, factor=rrg_init_weight)
+        else:
+            S.rrg = rrg_scherduler_cls(steps=n_rrg, start_val=rrg_init_weight, stop_val=0)
+        S.C = C = self.unet.config.in_channels
+        dev = self.device
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        S.T = len(ts)
+        self._timesteps = list(ts)
+        self._t_dev = ts.to(dev)
+        self._step_coef = [self.scheduler.step_coefficients(t) for t in ts]
+        S.R = R = int(resampling_steps)
+        if not 0 <= R <= host_rng.MAX_RESAMPLING_STEPS:
+            raise ValueError(f"resampling_steps must be in [0, {host_rng.MAX_RESAMPLING_STEPS}] (the per-pixel "
+                             f"last-covering-step table is int8), got {resampling_steps}")
+        S.repaint = bool(repaint_sampling) and R > 0
+        if S.repaint:
+            # undo_step is only ever entered with timesteps[i+1] (ED:1040): row 0 is a placeholder
+            rows = [self.scheduler.undo_coefficients(t) for t in ts[1:]]
+            self._undo_coef = torch.stack(rows[:1] + rows).to(dev) if rows else None
+        d0, d1 = self.default_size
+        self._time_ids.copy_(torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32))  # ED:232-246, 414-418
+        self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
+        self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
+        self._mark("setup_done")
+        S.Ks = sorted({R + 1, 1} if S.repaint else {R + 1})
+        if getattr(self, "_cn_scale", controlnet_conditioning_scale) != controlnet_conditioning_scale:
+            self._runner.entries.clear()  # the scale is a constant inside captured graphs
+        self._cn_scale = controlnet_conditioning_scale
+        S.guidance, S.drop_p = guidance_scale, 1 - new_p
+        S.norm = np.float32(2.0 / (C * P.Hl * P.Wl))
+        return S
+
+    def _program(self, S, prompts, negative_prompts, condition_image=None, trace=None, progress=_identity_progress,
+                 direct=True):
+        """Generator: the denoising loop of ONE image (ED:981-1078), yielding ``_ModelCall``s; returns the final latent.
+        All host RNG draws happen inside, in the reference's order."""
+        P = S.P
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        if isinstance(negative_prompts, str):
+            negative_prompts = [negative_prompts] * len(prompts)
+        un, pun = self.get_text_embeds(negative_prompts)
+        co, pco = self.get_text_embeds(prompts)
+        B = len(prompts)
+        # initial latent from the host generator (ED:998-1000)
+        x_host = self._stager.host((B, S.C, P.Hl, P.Wl), torch.float32)
+        x_host.normal_()
+        x = self._stager.upload(x_host, self.device)
+        emb = {K: self._embed_rows(K, P.views.V, un, co, pun, pco) for K in S.Ks}
+        cond = None
+        if condition_image is not None:
+            if self.controlnet is None:
+                raise ValueError("condition_image given but no controlnet was supplied")
+            cond = self._condition_rows(P, condition_image, B, S.Ks)
+        for i, t in enumerate(progress(self._timesteps)):
+            prev, x0, info = yield from self._phase_steps(P, x, i, S.R + 1, S.guidance, S.drop_p, emb, cond, direct)
+            cfg = S.guidance
+            if S.repaint and i < S.T - 1:  # ED:1038-1056
+                x = self._undo(prev, i + 1)
+                cfg = S.guidance / 3
+                prev, x0, info = yield from self._phase_steps(P, x, i, 1, cfg, S.drop_p, emb, cond, direct)
+            w_i = S.rrg(i)
+            if w_i > 10:  # ED:1061-1078
+                sb, sa = self._step_coef[i][0], self._step_coef[i][1]
+                nxt = torch.empty_like(prev)
+                ops.rrg_update(prev, x0, info["low_latent"], info["uncond_score"], info["low_direction"], P.up_row,
+                               P.up_col, nxt, np.float32(cfg), sb, sa, S.norm, np.float32(w_i))
+                x = nxt
+            else:
+                x = prev
+            if trace is not None:
+                trace.append(x.clone())
+        return x
+
     @_on_own_device
     @torch.no_grad()
     def generate_latents(self, prompts, negative_prompts="", height=768, width=768, num_inference_steps=50,
@@ -440,81 +577,89 @@ class ElasticDiffusion(nn.Module):
                          rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
                          progress=_identity_progress, condition_image=None, controlnet_conditioning_scale=1.0,
                          trace=None):
-        self._mark("start")
-        self.host_s = {"picks": 0.0, "phase_total": 0.0, "noise": 0.0, "stager_wait": 0.0}
-        self._stager.waited = 0.0
-        P = self._plan(height, width)
-        self.default_size = (4 * height, 4 * width)  # ED:969
-        n_rrg = num_inference_steps - int(num_inference_steps * rrg_stop_t)
-        if rrg_scherduler_cls is CosineScheduler or getattr(rrg_scherduler_cls, "__name__", "") == "CosineScheduler":
-            rrg = rrg_scherduler_cls(steps=n_rrg, cosine_scale=cosine_scale, factor=rrg_init_weight)
-        else:
-            rrg = rrg_scherduler_cls(steps=n_rrg, start_val=rrg_init_weight, stop_val=0)
-        if isinstance(prompts, str):
-            prompts = [prompts]
-        if isinstance(negative_prompts, str):
-            negative_prompts = [negative_prompts] * len(prompts)
-        un, pun = self.get_text_embeds(negative_prompts)
-        co, pco = self.get_text_embeds(prompts)
-        B, C = len(prompts), self.unet.config.in_channels
-        dev = self.device
-        # initial latent from the host generator (ED:998-1000), then the schedule
-        x_host = self._stager.host((B, C, P.Hl, P.Wl), torch.float32)
-        x_host.normal_()
-        x = self._stager.upload(x_host, dev)
-        ts = self.scheduler.set_timesteps(num_inference_steps)
-        T = len(ts)
-        self._timesteps = list(ts)
-        self._t_dev = ts.to(dev)
-        self._step_coef = [self.scheduler.step_coefficients(t) for t in ts]
-        R = int(resampling_steps)
-        if not 0 <= R <= host_rng.MAX_RESAMPLING_STEPS:
-            raise ValueError(f"resampling_steps must be in [0, {host_rng.MAX_RESAMPLING_STEPS}] (the per-pixel "
-                             f"last-covering-step table is int8), got {resampling_steps}")
-        repaint = bool(repaint_sampling) and R > 0
-        if repaint:
-            # undo_step is only ever entered with timesteps[i+1] (ED:1040): row 0 is a placeholder
-            rows = [self.scheduler.undo_coefficients(t) for t in ts[1:]]
-            self._undo_coef = torch.stack(rows[:1] + rows).to(dev) if rows else None
-        d0, d1 = self.default_size
-        self._time_ids.copy_(torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32))  # ED:232-246, 414-418
+        S = self._setup_run(height, width, num_inference_steps, guidance_scale, resampling_steps, new_p, rrg_stop_t,
+                            rrg_init_weight, rrg_scherduler_cls, cosine_scale, repaint_sampling,
+                            controlnet_conditioning_scale)
         self._runner.new_image()
-        self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
-        self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
-        self._mark("setup_done")
-        Ks = sorted({R + 1, 1} if repaint else {R + 1})
-        emb = {K: self._embed_rows(K, P.views.V, un, co, pun, pco) for K in Ks}
-        cond = None
-        if getattr(self, "_cn_scale", controlnet_conditioning_scale) != controlnet_conditioning_scale:
-            self._runner.entries.clear()  # the scale is a constant inside captured graphs
-        self._cn_scale = controlnet_conditioning_scale
-        if condition_image is not None:
-            if self.controlnet is None:
-                raise ValueError("condition_image given but no controlnet was supplied")
-            cond = self._condition_rows(P, condition_image, B, Ks)
-        norm = np.float32(2.0 / (C * P.Hl * P.Wl))
-        for i, t in enumerate(progress(self._timesteps)):
-            prev, x0, info = self._phase(P, x, i, R + 1, guidance_scale, 1 - new_p, emb, cond)
-            cfg = guidance_scale
-            if repaint and i < T - 1:  # ED:1038-1056
-                x = self._undo(prev, i + 1)
-                cfg = guidance_scale / 3
-                prev, x0, info = self._phase(P, x, i, 1, cfg, 1 - new_p, emb, cond)
-            w_i = rrg(i)
-            if w_i > 10:  # ED:1061-1078
-                sb, sa = self._step_coef[i][0], self._step_coef[i][1]
-                nxt = torch.empty_like(prev)
-                ops.rrg_update(prev, x0, info["low_latent"], info["uncond_score"], info["low_direction"], P.up_row,
-                               P.up_col, nxt, np.float32(cfg), sb, sa, norm, np.float32(w_i))
-                x = nxt
-            else:
-                x = prev
-            if trace is not None:
-                trace.append(x.clone())
+        x = self._drive(self._program(S, prompts, negative_prompts, condition_image, trace, progress, direct=True))
         self.last_latents = x
         self.host_s["blocked_ahead_of_gpu"] = self._stager.waited
         self._mark("loop_done")
         return x
+
+    @_on_own_device
+    @torch.no_grad()
+    def generate_latents_interleaved(self, jobs, in_flight=2, height=768, width=768, num_inference_steps=50,
+                                     guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2,
+                                     rrg_init_weight=1000, rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0,
+                                     repaint_sampling=True, controlnet_conditioning_scale=1.0, on_done=None):
+        """Several images of the SAME size / settings in flight at once (new; the reference has nothing like it).
+
+        ``jobs`` = list of dicts {prompts, negative_prompts="", seed, condition_image=None}.  Each job is one
+        ``_program`` with its own host RNG stream (``_HostRng``: exactly the stream ``seed_everything(seed)`` +
+        ``generate_latents`` would consume, so every image's latents are those of running it alone, up to the model's
+        own batch-shape dependent rounding).  Per tick, the pending model calls of all live programs -- e.g. the 20-row
+        phase A batch of one image and the 6-row RePaint batch of another -- are concatenated into ONE forward, which
+        is then row-sharded over the ranks like any other batch.  Why: with N ranks a lone image leaves 20/N and 6/N rows
+        per rank, where the UNet runs at a fraction of its batch-20 rate; m images in flight multiply the rows per
+        forward by ~m while the exchange stays one all-gather per tick.  Returns the final latents in job order
+        (``on_done(index, latent)`` is called as each finishes, e.g. to decode it)."""
+        S = self._setup_run(height, width, num_inference_steps, guidance_scale, resampling_steps, new_p, rrg_stop_t,
+                            rrg_init_weight, rrg_scherduler_cls, cosine_scale, repaint_sampling,
+                            controlnet_conditioning_scale)
+        self._runner.new_image()
+        results = [None] * len(jobs)
+        queue = list(range(len(jobs)))
+        live = []  # [job index, program, rng, pending call]
+
+        def start(j):
+            job = jobs[j]
+            rng = _HostRng(job["seed"])
+            prog = self._program(S, job["prompts"], job.get("negative_prompts", ""), job.get("condition_image"),
+                                 direct=False)
+            with rng:
+                call = next(prog)
+            live.append([j, prog, rng, call])
+
+        while queue and len(live) < max(1, in_flight):
+            start(queue.pop(0))
+        self.ticks = 0
+        while live:
+            # one fused forward per group of shape-compatible pending calls (normally exactly one group)
+            groups = {}
+            for ent in live:
+                c = ent[3]
+                groups.setdefault((tuple(c.rows.shape[1:]), c.cond is None), []).append(ent)
+            for ents in groups.values():
+                calls = [e[3] for e in ents]
+                sizes = [c.rows.shape[0] for c in calls]
+                if len(calls) == 1:
+                    c = calls[0]
+                    outs = [self._run_model(c.rows, c.t, c.text, c.pooled, c.cond, fresh_side=True)]
+                else:
+                    rows = torch.cat([c.rows for c in calls])
+                    t = torch.cat([c.t.reshape(1).expand(n) for c, n in zip(calls, sizes)])
+                    text = torch.cat([c.text for c in calls])
+                    pooled = torch.cat([c.pooled for c in calls])
+                    cond = None if calls[0].cond is None else torch.cat([c.cond for c in calls])
+                    outs = self._run_model(rows, t, text, pooled, cond, fresh_side=True).split(sizes)
+                self.ticks += 1
+                for ent, out in zip(ents, outs):
+                    j, prog, rng = ent[0], ent[1], ent[2]
+                    try:
+                        with rng:
+                            ent[3] = prog.send(out)
+                    except StopIteration as stop:
+                        results[j] = stop.value
+                        live.remove(ent)
+                        if on_done is not None:
+                            on_done(j, stop.value)
+                        if queue:
+                            start(queue.pop(0))
+        self.last_latents = results[-1] if results else None
+        self.host_s["blocked_ahead_of_gpu"] = self._stager.waited
+        self._mark("loop_done")
+        return results
 
     # ---- decode (ED:267-310) -----------------------------------------------------------------------
     @_on_own_device
@@ -541,7 +686,7 @@ class ElasticDiffusion(nn.Module):
             outs = [self.vae.decode(rows[a:a + tile_batch]).sample for a in range(0, rows.shape[0], tile_batch)]
             return torch.cat(outs).contiguous()
 
-        decoded = self.sharder.run(dec, tiles, None, None, None)
+        decoded = self.sharder.run(dec, tiles, None, None, None, out_like=((3, tp.Ts * s, tp.Ts * s), vdt))
         image = torch.empty(B, decoded.shape[1], Hl * s, Wl * s, device=self.device, dtype=torch.float32)
         rt, rs, ct, cs = tp.pixel_tables()
         ops.tile_accumulate_normalise(decoded, image, tp.n_col_tiles, self._dev_i32(rt), self._dev_i32(rs),

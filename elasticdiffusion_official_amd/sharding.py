@@ -14,17 +14,24 @@ per phase and no overlap machinery.  An all-gather (not a sum all-reduce of zero
 bit-identical to the single-GPU run: afterwards every rank holds exactly the tensor a 1-GPU run would have produced
 and continues with the replicated glue kernels (first-writer-wins scatter included).
 
-Ranks with no row (more ranks than rows) compute a duplicate of the last row so that every rank contributes an equal
-sized block (all_gather_into_tensor needs equal sizes); duplicates are dropped after the gather.
+Rows are split as evenly as possible (20 rows on 8 ranks: 3,3,3,3,2,2,2,2); a rank computes exactly the rows it owns --
+none at all when there are more ranks than rows -- and only the COMMUNICATION buffer is padded to the common block
+size all_gather_into_tensor needs (the pad rows are never computed and are dropped after the gather).
 """
 import torch
 import torch.distributed as dist
 
 
 def row_partition(n_rows, world_size):
-    """Contiguous, near-equal split: per = ceil(n/ws); rank r owns [r*per, min(n,(r+1)*per)).  -> (per, [(lo,hi)])"""
-    per = -(-n_rows // world_size)
-    spans = [(min(n_rows, r * per), min(n_rows, (r + 1) * per)) for r in range(world_size)]
+    """Contiguous balanced split: the first ``n % ws`` ranks own ``ceil(n/ws)`` rows, the rest ``floor(n/ws)``.
+    -> (per, [(lo,hi)]) with per = ceil(n/ws) = the block size of the exchange."""
+    base, extra = divmod(n_rows, world_size)
+    per = base + (1 if extra else 0)
+    spans, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < extra else 0)
+        spans.append((lo, hi))
+        lo = hi
     return per, spans
 
 
@@ -39,32 +46,52 @@ class RowSharder:
         else:
             self.world_size, self.rank = 1, 0
         self._ix_cache = {}
+        self.rows_computed = 0   # model rows this rank actually ran (bench.py reports it: no duplicated work)
+        self.rows_total = 0
 
-    def run(self, fn, x_rows, text=None, pooled=None, cond=None):
-        """fn(x, text, pooled, cond) -> out with out.shape[0] == x.shape[0]; returns the full output on every rank."""
-        if self.world_size == 1:
-            return fn(x_rows, text, pooled, cond)
+    def run(self, fn, x_rows, text=None, pooled=None, cond=None, *more, out_like=None):
+        """fn(x, text, pooled, cond, *more) -> out with out.shape[0] == x.shape[0]; returns the full output on every
+        rank.  Every side input is None or a tensor with one row per row of ``x_rows`` (sliced like it).
+        ``out_like`` = (shape_tail, dtype) of one output row, needed only by a rank that owns no row of this batch
+        (it cannot learn the output shape from a forward it never runs); defaults to the input's row shape / dtype."""
         n = x_rows.shape[0]
+        self.rows_total += n
+        if self.world_size == 1:
+            self.rows_computed += n
+            return fn(x_rows, text, pooled, cond, *more)
         per, spans = row_partition(n, self.world_size)
         lo, hi = spans[self.rank]
-        key = (n, str(x_rows.device))
-        if key not in self._ix_cache:  # index tensors are built once per batch shape (no per-step H2D copies)
-            sel = list(range(lo, hi)) + [n - 1] * (per - (hi - lo))  # pad with duplicates of the last row
-            keep = [r * per + k for r, (a, b) in enumerate(spans) for k in range(b - a)]
-            self._ix_cache[key] = (torch.as_tensor(sel, device=x_rows.device), torch.as_tensor(keep, device=x_rows.device))
-        ix, keep = self._ix_cache[key]
+        self.rows_computed += hi - lo
 
         def take(t):
-            return None if t is None else t.index_select(0, ix).contiguous()
+            return None if t is None else t[lo:hi].contiguous()
 
-        local = fn(take(x_rows), take(text), take(pooled), take(cond)).contiguous()
-        full = torch.empty((per * self.world_size,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        if local.is_cuda and dist.get_backend(self.group) == "gloo":
-            # test-only transport (two ranks sharing one GPU cannot use RCCL): gloo stages device tensors via the host
-            parts = list(full.view((self.world_size, per) + tuple(local.shape[1:])).unbind(0))
-            dist.all_gather(parts, local, group=self.group)
+        local = (fn(take(x_rows), take(text), take(pooled), take(cond), *(take(m) for m in more)).contiguous()
+                 if hi > lo else None)
+        if local is not None:
+            tail, dtype = tuple(local.shape[1:]), local.dtype
+        elif out_like is not None:
+            tail, dtype = tuple(out_like[0]), out_like[1]
         else:
-            dist.all_gather_into_tensor(full, local, group=self.group)
+            tail, dtype = tuple(x_rows.shape[1:]), x_rows.dtype
+        dev = x_rows.device
+        if local is not None and local.shape[0] == per:
+            send = local
+        else:  # short (or empty) share: pad the exchange block, not the compute
+            send = torch.empty((per,) + tail, dtype=dtype, device=dev)
+            if local is not None:
+                send[: hi - lo].copy_(local)
+        full = torch.empty((per * self.world_size,) + tail, dtype=dtype, device=dev)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test-only transport (two ranks sharing one GPU cannot use RCCL): gloo stages device tensors via the host
+            parts = list(full.view((self.world_size, per) + tail).unbind(0))
+            dist.all_gather(parts, send, group=self.group)
+        else:
+            dist.all_gather_into_tensor(full, send, group=self.group)
         if per * self.world_size == n:
             return full
-        return full.index_select(0, keep).contiguous()
+        key = (n, str(dev))
+        if key not in self._ix_cache:  # built once per batch shape (no per-step H2D copies)
+            keep = [r * per + k for r, (a, b) in enumerate(spans) for k in range(b - a)]
+            self._ix_cache[key] = torch.as_tensor(keep, device=dev)
+        return full.index_select(0, self._ix_cache[key]).contiguous()

@@ -51,6 +51,8 @@ class FakeUNet(nn.Module):
     def forward(self, x, t, encoder_hidden_states=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
         tt = torch.as_tensor(t, dtype=torch.float32, device=x.device) / 1000.0
+        if tt.dim() > 0:  # one timestep per row (fused batches of several images in flight)
+            tt = tt.view(-1, 1, 1, 1)
         e = self.emb(encoder_hidden_states.to(x.dtype).mean(dim=1))  # (B,4)
         pos = self.pos
         if pos.shape[-2:] != x.shape[-2:]:

@@ -373,3 +373,29 @@ def test_edge_geometries_and_prompt_batches_vs_oracle(sd, sample, H, W, B, R, pa
     assert z.shape == want.shape == (B, 4, H // 8, W // 8)
     assert rel_l2(z, want) < 1e-4, rel_l2(z, want)
     assert torch.equal(tail, torch.rand(3))
+
+
+def test_interleaved_images_equal_running_each_alone():
+    """generate_latents_interleaved: three images (different prompts / seeds), two in flight -- the 20-row phase of one
+    fused with the RePaint phase of the other into one forward with per-row timesteps.  Every image must come out as
+    if it had run alone with seed_everything(seed) (its own host RNG stream), and the caller's RNG state is untouched."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    kw = dict(height=512, width=1024, num_inference_steps=3, guidance_scale=10.0, resampling_steps=2, new_p=0.3,
+              rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0, repaint_sampling=True)
+    pipe = ElasticDiffusion(DEV, "1.5", view_batch_size=4, unet=FakeUNet(64), vae=FakeVAE())
+    jobs = [dict(prompts="a cat", negative_prompts="blurry", seed=11), dict(prompts="a dog", seed=12),
+            dict(prompts=["two", "prompts"], seed=13)]
+    alone = []
+    for j in jobs:
+        pipe.seed_everything(j["seed"])
+        alone.append(pipe.generate_latents(j["prompts"], j.get("negative_prompts", ""), **kw).clone())
+    torch.manual_seed(777)
+    np.random.seed(777)
+    done = []
+    got = pipe.generate_latents_interleaved(jobs, in_flight=2, on_done=lambda i, z: done.append(i), **kw)
+    assert torch.equal(torch.rand(3), torch.manual_seed(777) and torch.rand(3))  # outer torch stream untouched
+    assert sorted(done) == [0, 1, 2] and pipe.ticks < 3 * (2 * 3 - 1)           # calls were actually fused
+    for z, want in zip(got, alone):
+        assert z.shape == want.shape
+        assert rel_l2(z, want) < 1e-5, rel_l2(z, want)
+    assert pipe._runner.stats()["eager"] == 0

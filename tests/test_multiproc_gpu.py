@@ -85,3 +85,35 @@ def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
         np.testing.assert_array_equal(tail, g[f"{name}/rng_tail"])
         np.testing.assert_array_equal(z, ret[0][0])      # all ranks bit-identical
         np.testing.assert_array_equal(img, ret[0][1])
+
+
+@pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "2", "--in-flight", "2"],
+                                   ["--gpus", "4", "--shard-group", "2", "--in-flight", "2"]])
+def test_bench_multi_rank_rehearsal(flags):
+    """bench.py's N > 1 control flow end to end (process groups, row sharding, images in flight, the alternative
+    layouts measured after the timed region, max-over-ranks timing, rank 0 printing ONE JSON line) with N ranks sharing
+    this box's single GPU over gloo and the reduced-width architecture.  The numbers mean nothing; the point is that
+    the exact code path the driver launches on 2/4/8 GPUs (there over RCCL) runs and reports what it should."""
+    import json
+    import subprocess
+    import sys
+    n = int(flags[1])
+    env = dict(os.environ, ED_DIST_BACKEND="gloo", MIOPEN_FIND_MODE="FAST", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", *flags, "--steps", "2", "--warmup", "1", "--small",
+           "--workload", "sd15_512x1024", "--timesteps", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["scaling"] == "strong" and d["finite_output"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-3
+    g = d["config"]["shard_group"]
+    assert g == (2 if "--shard-group" in flags else n)
+    comp, tot = d["rows_computed_over_rows_total_rank0"]
+    assert 0 < comp <= -(-tot // g) + 2 * 50   # a rank computes ~1/g of the rows, never duplicates of others' rows
+    assert d["graphs"]["eager"] == 0
+    if not ("--in-flight" not in flags and g == n):
+        assert "view_parallel_one_image" in d["layouts"]

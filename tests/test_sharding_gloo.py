@@ -53,8 +53,10 @@ def _worker(rank, world, port, n_rows_list, ret):
                 full = sh.run(fn, x, text if with_side else None, pooled if with_side else None, cond if with_side else None)
                 want = _model(x, text if with_side else None, pooled if with_side else None, cond if with_side else None)
                 ok = ok and torch.equal(full, want)
-            per, _ = row_partition(n, world)
-            ok = ok and all(c == per for c in calls)  # every rank computes the same (padded) number of rows
+            _, spans = row_partition(n, world)
+            own = spans[rank][1] - spans[rank][0]
+            # a rank runs the model on exactly the rows it owns: no duplicated rows, no call at all when it owns none
+            ok = ok and calls == ([own, own] if own else [])
         ret[rank] = ok
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,51 @@
+"""Summarise rocprofv3 --pmc passes (one *_counter_collection.csv per pass) into profiles/<name>.json:
+mean counter value per launch for the hand-written kernels (second half of the launches: the first repetition warms).
+
+usage: pmc_summarise.py out.json pass_dir [pass_dir ...]
+HBM bytes per launch follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are KiB on rocprofv3; on gfx950
+FETCH_SIZE tallies the 128-B requests of wide (16 B / lane) coalesced reads at 64 B, so hbm_bytes = (2*FETCH + WRITE)*1024
+for these streaming kernels (all of them read with 16-byte vectors); the uncorrected sum is kept next to it."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ENTRY = {"k_flash_attn_fwd": "ed_flash_attention", "k_geglu": "ed_geglu", "k_groupnorm": "ed_groupnorm",
+         "k_layernorm": "ed_layernorm", "k_add_layernorm": "ed_add_layernorm", "k_tokens_add_nchw": "ed_tokens_add_nchw",
+         "k_pick_assemble": "ed_pick_assemble", "k_gather_windows": "ed_gather_views", "k_undo_step": "ed_undo_step"}
+
+
+def entry_of(kernel):
+    for k, v in ENTRY.items():
+        if re.search(r"\b" + k + r"\b|" + k + "[A-Z<_]", kernel) or k in kernel:
+            return v
+    return None
+
+
+out_path, dirs = sys.argv[1], sys.argv[2:]
+vals = defaultdict(lambda: defaultdict(list))
+for d in dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            e = entry_of(row.get("Kernel_Name", ""))
+            if e:
+                vals[e][row["Counter_Name"]].append(float(row["Counter_Value"]))
+res = {}
+for e, counters in vals.items():
+    r = {}
+    for c, v in counters.items():
+        half = v[len(v) // 2:]
+        r[c + "_mean"] = sum(half) / len(half)
+        r["launches_counted"] = len(half)
+    if "FETCH_SIZE_mean" in r and "WRITE_SIZE_mean" in r:
+        r["hbm_bytes_per_launch_mean"] = round((2 * r["FETCH_SIZE_mean"] + r["WRITE_SIZE_mean"]) * 1024)
+        r["hbm_bytes_per_launch_uncorrected"] = round((r["FETCH_SIZE_mean"] + r["WRITE_SIZE_mean"]) * 1024)
+    if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in r and "SQ_BUSY_CU_CYCLES_mean" in r and r["SQ_BUSY_CU_CYCLES_mean"]:
+        r["mfma_busy_over_cu_busy"] = round(r["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / r["SQ_BUSY_CU_CYCLES_mean"], 4)
+    res[e] = r
+json.dump({"note": __doc__.strip().split("usage")[0].strip() + " Launch mix: one phase-A (20-row) and one phase-B (6-row) "
+                   "SDXL forward of the 1024x2048 workload (tools/pmc_unet.py).", "kernels": res}, open(out_path, "w"), indent=1)
+print(json.dumps({k: {c: round(v, 1) if isinstance(v, float) else v for c, v in r.items()} for k, r in res.items()}, indent=1))

@@ -1,0 +1,23 @@
+"""One eager SDXL UNet forward of each phase batch (20 rows, 6 rows) at the headline workload's shapes, for
+`rocprofv3 --pmc` passes over the hand-written kernels inside the UNet (flash attention, GEGLU, GroupNorm, LayerNorm,
+fused adds): the launch mix is exactly the per-timestep mix of bench.py's workload."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import elasticdiffusion_official_amd  # noqa: F401
+from elasticdiffusion_official_amd import ElasticDiffusion
+
+pipe = ElasticDiffusion("cuda:0", "XL1.0", view_batch_size=16, use_graphs=False)
+cfg = pipe.unet.config
+with torch.no_grad():
+    for rep in range(2):  # first repetition warms (kernel load, fused weights); rocprofv3 sees both, the summary skips it
+        for rows in (20, 6):
+            x = torch.randn(rows, 4, 128, 128, device="cuda", dtype=torch.bfloat16)
+            txt = torch.randn(rows, 77, cfg.cross_attention_dim, device="cuda", dtype=torch.bfloat16)
+            pl = torch.randn(rows, cfg.pooled_projection_dim, device="cuda", dtype=torch.bfloat16)
+            pipe._forward_rows(x, torch.tensor(500, device="cuda"), txt, pl, None)
+        torch.cuda.synchronize()
+print("done")
