@@ -346,9 +346,6 @@ def main():
             cached_s = timed(pipe, 2001, 1, 1, 1, 0)
             pipe.cache_backgrounds = False
             pipe._frame_cache.clear()
-        if world == 1 and m == 1:
-            run_images(pipe, [3000, 3001], 2)  # capture the fused-batch graph shapes
-            layouts["1gpu_two_images_in_flight"] = dict(images=2, images_per_s=round(2 / timed(pipe, 3002, 2, 2, 1, 0), 5))
         if world > 1:
             # the same N GPUs in the other layouts, so that a scaling record cannot pass one off as another
             alts = []

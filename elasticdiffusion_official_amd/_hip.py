@@ -40,12 +40,18 @@ SIGNATURES = {
     "ed_tile_gather_pad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp],
     "ed_tile_accumulate_normalise": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ed_geglu": [_vp, _vp, _i, _i64, _i, _vp],
-    "ed_groupnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ed_groupnorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ed_bias_residual_add": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ed_add_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
     "ed_tokens_add_nchw": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ed_layernorm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
     "ed_groupnorm_nhwc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc_workspace": [_i, _i, _i, _i],
+    "ed_assemble_rows": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
+                         _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_phase_epilogue": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f,
+                          _vp],
     "ed_flash_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp],
 }
 

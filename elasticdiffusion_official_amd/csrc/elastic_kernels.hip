@@ -95,12 +95,10 @@ inline int done() { return (int)hipGetLastError(); }
 
 // ---- ed_gather_views / ed_tile_gather_pad ----------------------------------------------------------
 template <typename Tag>
-__global__ void __launch_bounds__(ED_BLOCK)
-k_gather_windows(const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
+__device__ __forceinline__ void gather_windows_body(int64_t t, const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
                  const int32_t* __restrict__ wy0, const int32_t* __restrict__ wx0, int V, int Sh, int Sw,
                  int PH, int PW, int off_y, int off_x, const float* __restrict__ frame, float divisor, int use_div) {
   int64_t n = (int64_t)V * B * C * PH * PW;
-  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
   if (t >= n) return;
   int x = (int)(t % PW);
   int64_t r = t / PW;
@@ -126,15 +124,21 @@ k_gather_windows(const float* __restrict__ latent, void* __restrict__ out, int B
   st<Tag>(out, t, val);
 }
 
-// 4 consecutive x per thread; requires PW, Sw, off_x multiples of 4 (a group is entirely inside or outside the window)
 template <typename Tag>
 __global__ void __launch_bounds__(ED_BLOCK)
-k_gather_windows_x4(const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
+k_gather_windows(const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
+                 const int32_t* __restrict__ wy0, const int32_t* __restrict__ wx0, int V, int Sh, int Sw,
+                 int PH, int PW, int off_y, int off_x, const float* __restrict__ frame, float divisor, int use_div) {
+  gather_windows_body<Tag>((int64_t)blockIdx.x * ED_BLOCK + threadIdx.x, latent, out, B, C, H, W, wy0, wx0, V, Sh, Sw, PH, PW, off_y, off_x, frame, divisor, use_div);
+}
+
+// 4 consecutive x per thread; requires PW, Sw, off_x multiples of 4 (a group is entirely inside or outside the window)
+template <typename Tag>
+__device__ __forceinline__ void gather_windows_x4_body(int64_t t, const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
                     const int32_t* __restrict__ wy0, const int32_t* __restrict__ wx0, int V, int Sh, int Sw,
                     int PH, int PW, int off_y, int off_x, const float* __restrict__ frame, float divisor, int use_div) {
   int PW4 = PW >> 2;
   int64_t n = (int64_t)V * B * C * PH * PW4;
-  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
   if (t >= n) return;
   int x = (int)(t % PW4) << 2;
   int64_t r = t / PW4;
@@ -163,6 +167,14 @@ k_gather_windows_x4(const float* __restrict__ latent, void* __restrict__ out, in
     val[0] = val[1] = val[2] = val[3] = 0.0f;
   }
   st4<Tag>(out, t << 2, val[0], val[1], val[2], val[3]);
+}
+
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_gather_windows_x4(const float* __restrict__ latent, void* __restrict__ out, int B, int C, int H, int W,
+                    const int32_t* __restrict__ wy0, const int32_t* __restrict__ wx0, int V, int Sh, int Sw,
+                    int PH, int PW, int off_y, int off_x, const float* __restrict__ frame, float divisor, int use_div) {
+  gather_windows_x4_body<Tag>((int64_t)blockIdx.x * ED_BLOCK + threadIdx.x, latent, out, B, C, H, W, wy0, wx0, V, Sh, Sw, PH, PW, off_y, off_x, frame, divisor, use_div);
 }
 
 // ---- ed_scatter_centres ----------------------------------------------------------------------------
@@ -202,13 +214,11 @@ k_scatter_centres(const void* __restrict__ pred, float* __restrict__ local, int 
 
 // ---- ed_pick_assemble ------------------------------------------------------------------------------
 template <typename Tag>
-__global__ void __launch_bounds__(ED_BLOCK)
-k_pick_assemble(const float* __restrict__ latent, const uint8_t* __restrict__ idx,
+__device__ __forceinline__ void pick_assemble_body(int64_t t, const float* __restrict__ latent, const uint8_t* __restrict__ idx,
                 const int32_t* __restrict__ src_row, const int32_t* __restrict__ src_col,
                 const float* __restrict__ frame, void* __restrict__ out, float* __restrict__ low,
                 int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x) {
   int64_t n = (int64_t)K * B * C * PH * PW;
-  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
   if (t >= n) return;
   int x = (int)(t % PW);
   int64_t r = t / PW;
@@ -237,16 +247,23 @@ k_pick_assemble(const float* __restrict__ latent, const uint8_t* __restrict__ id
   st<Tag>(out, row_c * C * plane + e, val);
 }
 
-// 4 consecutive x per thread; requires PW, w, off_x multiples of 4
 template <typename Tag>
 __global__ void __launch_bounds__(ED_BLOCK)
-k_pick_assemble_x4(const float* __restrict__ latent, const uint8_t* __restrict__ idx,
+k_pick_assemble(const float* __restrict__ latent, const uint8_t* __restrict__ idx,
+                const int32_t* __restrict__ src_row, const int32_t* __restrict__ src_col,
+                const float* __restrict__ frame, void* __restrict__ out, float* __restrict__ low,
+                int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x) {
+  pick_assemble_body<Tag>((int64_t)blockIdx.x * ED_BLOCK + threadIdx.x, latent, idx, src_row, src_col, frame, out, low, K, B, C, H, W, h, w, PH, PW, off_y, off_x);
+}
+
+// 4 consecutive x per thread; requires PW, w, off_x multiples of 4
+template <typename Tag>
+__device__ __forceinline__ void pick_assemble_x4_body(int64_t t, const float* __restrict__ latent, const uint8_t* __restrict__ idx,
                    const int32_t* __restrict__ src_row, const int32_t* __restrict__ src_col,
                    const float* __restrict__ frame, void* __restrict__ out, float* __restrict__ low,
                    int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x) {
   int PW4 = PW >> 2;
   int64_t n = (int64_t)K * B * C * PH * PW4;
-  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
   if (t >= n) return;
   int x = (int)(t % PW4) << 2;
   int64_t r = t / PW4;
@@ -284,6 +301,15 @@ k_pick_assemble_x4(const float* __restrict__ latent, const uint8_t* __restrict__
   int64_t row_c = ((int64_t)k * 2 + 1) * B + b;
   st4<Tag>(out, row_u * C * plane_sz + e0, val[0], val[1], val[2], val[3]);
   st4<Tag>(out, row_c * C * plane_sz + e0, val[0], val[1], val[2], val[3]);
+}
+
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_pick_assemble_x4(const float* __restrict__ latent, const uint8_t* __restrict__ idx,
+                   const int32_t* __restrict__ src_row, const int32_t* __restrict__ src_col,
+                   const float* __restrict__ frame, void* __restrict__ out, float* __restrict__ low,
+                   int K, int B, int C, int H, int W, int h, int w, int PH, int PW, int off_y, int off_x) {
+  pick_assemble_x4_body<Tag>((int64_t)blockIdx.x * ED_BLOCK + threadIdx.x, latent, idx, src_row, src_col, frame, out, low, K, B, C, H, W, h, w, PH, PW, off_y, off_x);
 }
 
 // ---- ed_unpad_direction ----------------------------------------------------------------------------
@@ -430,6 +456,144 @@ k_cfg_ddim_s(const float* __restrict__ local, const float* __restrict__ dir, con
   ddim_one(local[t], dir[t], x[t], g, sb, sa, sp, sd, p, o);
   prev[t] = p;
   x0[t] = o;
+}
+
+// ---- ed_assemble_rows: ed_pick_assemble + ed_gather_views in ONE launch ----------------------------
+// The first `pick_blocks` workgroups assemble the K CFG pairs, the rest gather the V context crops; both write rows of
+// the same fused model batch.  PX4 / GX4: the 4-wide variants (host checks the alignment conditions per part).
+struct AssembleArgs {
+  const float* latent;
+  int B, C, H, W;
+  // global (pick) part
+  const uint8_t* idx;
+  const int32_t *src_row, *src_col;
+  const float* gframe;
+  void* g_out;
+  float* low;
+  int K, h, w, gPH, gPW, g_off_y, g_off_x;
+  // view part
+  const int32_t *win_y0, *win_x0;
+  const float* vframe;
+  void* v_out;
+  int V, Sh, Sw, vPH, vPW, v_off_y, v_off_x;
+  int pick_blocks;
+};
+
+template <typename Tag, bool PX4, bool GX4>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_assemble_rows(const AssembleArgs a) {
+  if ((int)blockIdx.x < a.pick_blocks) {
+    int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+    if (PX4)
+      pick_assemble_x4_body<Tag>(t, a.latent, a.idx, a.src_row, a.src_col, a.gframe, a.g_out, a.low, a.K, a.B, a.C, a.H, a.W,
+                                 a.h, a.w, a.gPH, a.gPW, a.g_off_y, a.g_off_x);
+    else
+      pick_assemble_body<Tag>(t, a.latent, a.idx, a.src_row, a.src_col, a.gframe, a.g_out, a.low, a.K, a.B, a.C, a.H, a.W,
+                              a.h, a.w, a.gPH, a.gPW, a.g_off_y, a.g_off_x);
+  } else {
+    int64_t t = (int64_t)((int)blockIdx.x - a.pick_blocks) * ED_BLOCK + threadIdx.x;
+    if (GX4)
+      gather_windows_x4_body<Tag>(t, a.latent, a.v_out, a.B, a.C, a.H, a.W, a.win_y0, a.win_x0, a.V, a.Sh, a.Sw, a.vPH, a.vPW,
+                                  a.v_off_y, a.v_off_x, a.vframe, 1.0f, 0);
+    else
+      gather_windows_body<Tag>(t, a.latent, a.v_out, a.B, a.C, a.H, a.W, a.win_y0, a.win_x0, a.V, a.Sh, a.Sw, a.vPH, a.vPW,
+                               a.v_off_y, a.v_off_x, a.vframe, 1.0f, 0);
+  }
+}
+
+// ---- ed_phase_epilogue: unpad + fill + scatter + CFG/DDIM (+ RRG) in ONE launch ---------------------
+// Everything downstream of the model call is a per-output-pixel gather: which resampling step covers the pixel (stamp
+// table) -> cond - uncond of that step's rows; the first non-zero covering view centre; the DDIM update; optionally the
+// reduced-resolution-guidance term of ED:886-940 / ED:1078.  Same fp32 operation order as the separate kernels
+// (__f*_rn, no contraction): results are bit-identical to ed_unpad_direction -> ed_fill_directions ->
+// ed_scatter_centres -> ed_cfg_ddim_step [-> ed_rrg_update].
+struct EpilogueArgs {
+  const void *g_out, *v_out;
+  const float* x;
+  const int8_t* stamp;
+  const int32_t *inv_row, *inv_col, *up_row, *up_col, *down_row, *down_col;
+  const int32_t *row_blk, *row_src, *col_blk, *col_src;
+  const float* low_latent;                       // [B,C,h,w] last picked reduced latent (RRG) or NULL
+  float *prev, *x0, *x_next, *low_dir, *uncond_last, *direction, *local;  // x_next/direction/local optional
+  int K, B, C, H, W, h, w, gPH, gPW, g_off_y, g_off_x, vPH, vPW, ncb;
+  float g, sb, sa, sp, sd, rrg_norm, rrg_weight;
+};
+
+template <typename Tag>
+__device__ __forceinline__ float direction_at(const EpilogueArgs& a, int b, int c, int Y, int X) {
+  int k = last_covering_step(a.stamp, a.inv_row, a.inv_col, a.K, a.w, Y, X);
+  int64_t plane = (int64_t)a.gPH * a.gPW;
+  int64_t e = ((int64_t)c * a.gPH + (a.up_row[Y] + a.g_off_y)) * a.gPW + (a.up_col[X] + a.g_off_x);
+  float u = ld<Tag>(a.g_out, (((int64_t)k * 2 + 0) * a.B + b) * a.C * plane + e);
+  float cd = ld<Tag>(a.g_out, (((int64_t)k * 2 + 1) * a.B + b) * a.C * plane + e);
+  return __fsub_rn(cd, u);
+}
+
+template <typename Tag>
+__global__ void __launch_bounds__(ED_BLOCK)
+k_phase_epilogue(const EpilogueArgs a) {
+  const int64_t nfull = (int64_t)a.B * a.C * a.H * a.W;
+  const int64_t nlow = (int64_t)a.B * a.C * a.h * a.w;
+  int64_t t = (int64_t)blockIdx.x * ED_BLOCK + threadIdx.x;
+  if (t >= nfull + nlow) return;
+  if (t >= nfull) {  // reduced-resolution by-products for RRG / the caller: direction sampled at the nearest-downsample points
+    int64_t u = t - nfull;
+    int j = (int)(u % a.w);
+    int64_t r = u / a.w;
+    int i = (int)(r % a.h);
+    r /= a.h;
+    int c = (int)(r % a.C);
+    int b = (int)(r / a.C);
+    if (a.low_dir) a.low_dir[u] = direction_at<Tag>(a, b, c, a.down_row[i], a.down_col[j]);
+    if (a.uncond_last) {
+      int64_t plane = (int64_t)a.gPH * a.gPW;
+      int64_t e = ((int64_t)c * a.gPH + (i + a.g_off_y)) * a.gPW + (j + a.g_off_x);
+      a.uncond_last[u] = ld<Tag>(a.g_out, (((int64_t)(a.K - 1) * 2 + 0) * a.B + b) * a.C * plane + e);
+    }
+    return;
+  }
+  int X = (int)(t % a.W);
+  int64_t r = t / a.W;
+  int Y = (int)(r % a.H);
+  r /= a.H;
+  int c = (int)(r % a.C);
+  int b = (int)(r / a.C);
+  // local unconditional score: first covering view whose centre value is non-zero (ED:852-861)
+  float loc = 0.0f;
+  bool settled = false;
+#pragma unroll
+  for (int kr = 0; kr < 2; ++kr) {
+    int rb = a.row_blk[Y * 2 + kr];
+    if (rb < 0 || settled) continue;
+    int sy = a.row_src[Y * 2 + kr];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      int cb = a.col_blk[X * 2 + kc];
+      if (cb < 0 || settled) continue;
+      int sx = a.col_src[X * 2 + kc];
+      int64_t row = (int64_t)(rb * a.ncb + cb) * a.B + b;
+      loc = ld<Tag>(a.v_out, ((row * a.C + c) * a.vPH + sy) * a.vPW + sx);
+      if (loc != 0.0f) settled = true;
+    }
+  }
+  float d = direction_at<Tag>(a, b, c, Y, X);
+  float pv, z0;
+  ddim_one(loc, d, a.x[t], a.g, a.sb, a.sa, a.sp, a.sd, pv, z0);
+  a.prev[t] = pv;
+  a.x0[t] = z0;
+  if (a.direction) a.direction[t] = d;
+  if (a.local) a.local[t] = loc;
+  if (a.x_next) {  // ED:886-940 closed form + ED:1078, as k_rrg_update
+    int i = a.up_row[Y], j = a.up_col[X];
+    int64_t plane = (int64_t)a.gPH * a.gPW;
+    int64_t e = ((int64_t)c * a.gPH + (i + a.g_off_y)) * a.gPW + (j + a.g_off_x);
+    float lu = ld<Tag>(a.g_out, (((int64_t)(a.K - 1) * 2 + 0) * a.B + b) * a.C * plane + e);
+    float ldir = direction_at<Tag>(a, b, c, a.down_row[i], a.down_col[j]);
+    float eps = __fadd_rn(lu, __fmul_rn(a.g, ldir));
+    float up = __fdiv_rn(__fsub_rn(a.low_latent[(((int64_t)b * a.C + c) * a.h + i) * a.w + j], __fmul_rn(a.sb, eps)), a.sa);
+    float grad = __fmul_rn(__fmul_rn(a.rrg_norm, __fsub_rn(z0, up)), a.rrg_weight);
+    a.x_next[t] = __fadd_rn(pv, -grad);
+  }
 }
 
 // ---- ed_undo_step ----------------------------------------------------------------------------------
@@ -649,6 +813,66 @@ int ed_pick_assemble(const float* latent, const uint8_t* idx, const int32_t* src
   }
   ED_LAUNCH_T(dtype, k_pick_assemble, n, latent, idx, src_row, src_col, frame, out, low, K, B, C, H, W, h, w, PH, PW,
                                          off_y, off_x);
+  return done();
+}
+
+int ed_assemble_rows(const float* latent, int B, int C, int H, int W, const uint8_t* idx, const int32_t* src_row,
+                     const int32_t* src_col, const float* gframe, void* g_rows, float* low, int K, int h, int w, int gPH,
+                     int gPW, int g_off_y, int g_off_x, const int32_t* win_y0, const int32_t* win_x0,
+                     const float* vframe, void* v_rows, int V, int Sh, int Sw, int vPH, int vPW, int v_off_y, int v_off_x,
+                     int dtype, void* stream) {
+  int64_t n_g = (int64_t)K * B * C * gPH * gPW, n_v = (int64_t)V * B * C * vPH * vPW;
+  if (n_g + n_v == 0) return 0;
+  bool px4 = (gPW & 3) == 0 && (w & 3) == 0 && (g_off_x & 3) == 0 && aligned16(g_rows) && aligned16(idx) &&
+             (!gframe || aligned16(gframe)) && (!low || aligned16(low));
+  bool gx4 = (vPW & 3) == 0 && (Sw & 3) == 0 && (v_off_x & 3) == 0 && aligned16(v_rows) && (!vframe || aligned16(vframe));
+  AssembleArgs a;
+  a.latent = latent, a.B = B, a.C = C, a.H = H, a.W = W;
+  a.idx = idx, a.src_row = src_row, a.src_col = src_col, a.gframe = gframe, a.g_out = g_rows, a.low = low;
+  a.K = K, a.h = h, a.w = w, a.gPH = gPH, a.gPW = gPW, a.g_off_y = g_off_y, a.g_off_x = g_off_x;
+  a.win_y0 = win_y0, a.win_x0 = win_x0, a.vframe = vframe, a.v_out = v_rows;
+  a.V = V, a.Sh = Sh, a.Sw = Sw, a.vPH = vPH, a.vPW = vPW, a.v_off_y = v_off_y, a.v_off_x = v_off_x;
+  a.pick_blocks = n_g ? grid_for(px4 ? n_g >> 2 : n_g) : 0;
+  int view_blocks = n_v ? grid_for(gx4 ? n_v >> 2 : n_v) : 0;
+  dim3 grid(a.pick_blocks + view_blocks), block(ED_BLOCK);
+  hipStream_t st_ = (hipStream_t)stream;
+#define ED_ASM(T)                                                              \
+  if (px4 && gx4) k_assemble_rows<T, true, true><<<grid, block, 0, st_>>>(a);  \
+  else if (px4) k_assemble_rows<T, true, false><<<grid, block, 0, st_>>>(a);   \
+  else if (gx4) k_assemble_rows<T, false, true><<<grid, block, 0, st_>>>(a);   \
+  else k_assemble_rows<T, false, false><<<grid, block, 0, st_>>>(a);
+  switch (dtype) {
+    case ED_F32: ED_ASM(F32) break;
+    case ED_F16: ED_ASM(F16) break;
+    case ED_BF16: ED_ASM(BF16) break;
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef ED_ASM
+  return done();
+}
+
+int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const float* x, const int8_t* stamp,
+                      const int32_t* inv_row, const int32_t* inv_col, const int32_t* up_row, const int32_t* up_col,
+                      const int32_t* down_row, const int32_t* down_col, const int32_t* row_blk, const int32_t* row_src,
+                      const int32_t* col_blk, const int32_t* col_src, const float* low_latent, float* prev, float* x0,
+                      float* x_next, float* low_dir, float* uncond_last, float* direction, float* local, int K, int B,
+                      int C, int H, int W, int h, int w, int gPH, int gPW, int g_off_y, int g_off_x, int vPH, int vPW,
+                      int n_col_blocks, float g, float sqrt_beta_t, float sqrt_alpha_t, float sqrt_alpha_prev,
+                      float sqrt_1m_alpha_prev, float rrg_norm, float rrg_weight, void* stream) {
+  int64_t n = (int64_t)B * C * H * W + (int64_t)B * C * h * w;
+  if ((int64_t)B * C * H * W == 0) return 0;
+  if (x_next && !low_latent) return (int)hipErrorInvalidValue;
+  EpilogueArgs a;
+  a.g_out = g_out, a.v_out = v_out, a.x = x, a.stamp = stamp;
+  a.inv_row = inv_row, a.inv_col = inv_col, a.up_row = up_row, a.up_col = up_col, a.down_row = down_row, a.down_col = down_col;
+  a.row_blk = row_blk, a.row_src = row_src, a.col_blk = col_blk, a.col_src = col_src;
+  a.low_latent = low_latent, a.prev = prev, a.x0 = x0, a.x_next = x_next, a.low_dir = low_dir, a.uncond_last = uncond_last;
+  a.direction = direction, a.local = local;
+  a.K = K, a.B = B, a.C = C, a.H = H, a.W = W, a.h = h, a.w = w, a.gPH = gPH, a.gPW = gPW, a.g_off_y = g_off_y;
+  a.g_off_x = g_off_x, a.vPH = vPH, a.vPW = vPW, a.ncb = n_col_blocks;
+  a.g = g, a.sb = sqrt_beta_t, a.sa = sqrt_alpha_t, a.sp = sqrt_alpha_prev, a.sd = sqrt_1m_alpha_prev;
+  a.rrg_norm = rrg_norm, a.rrg_weight = rrg_weight;
+  ED_LAUNCH_T(dtype, k_phase_epilogue, n, a);
   return done();
 }
 

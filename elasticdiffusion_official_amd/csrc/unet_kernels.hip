@@ -77,24 +77,30 @@ __device__ __forceinline__ Welford merge(Welford a, Welford b) {
 
 // ``cb`` (optional): per-channel bias of this (sample, group), cb[c - g*cpg]; the normalised tensor is
 // round16(x + cb[c]) -- what torch's 16-bit `h + temb[:, :, None, None]` (ResnetBlock2D) hands to norm2.
+// ``kb`` (optional): the producing convolution's bias, kb[c]: MIOpen leaves the bias of a convolution to a separate
+// broadcast-add kernel, so the convolution is run bias-free and the add is folded in here, rounded to 16 bit like that
+// kernel's output was, BEFORE the time-embedding add (which torch also rounds).
 template <typename T>
-__device__ __forceinline__ float biased(uint16_t x, float cb, bool has_cb) {
+__device__ __forceinline__ float biased(uint16_t x, float kb, bool has_kb, float cb, bool has_cb) {
   float f = T::to_f32(x);
+  if (has_kb) f = T::to_f32(T::from_f32(f + kb));
   return has_cb ? T::to_f32(T::from_f32(f + cb)) : f;
 }
 
 template <typename T>
 __device__ __forceinline__ void group_stats(const uint16_t* __restrict__ chunk, int64_t len, int HW,
-                                            const uint16_t* __restrict__ cb, float eps, float& mean, float& rstd) {
+                                            const uint16_t* __restrict__ kb, const uint16_t* __restrict__ cb, float eps,
+                                            float& mean, float& rstd) {
   // pass 1: per-thread sum / sum of squares over 16-byte vectors (few hundred elements per thread), then Chan merge
   float s = 0.f, ss = 0.f, cnt = 0.f;
-  const bool has_cb = cb != nullptr;
+  const bool has_cb = cb != nullptr, has_kb = kb != nullptr;
   for (int64_t i = (int64_t)threadIdx.x * 8; i < len; i += GN_THREADS * 8) {
     U16x8 v = *reinterpret_cast<const U16x8*>(chunk + i);
     const float cbv = has_cb ? T::to_f32(cb[i / HW]) : 0.f;  // HW % 8 == 0: a vector never straddles channels
+    const float kbv = has_kb ? T::to_f32(kb[i / HW]) : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float f = biased<T>(v.v[e], cbv, has_cb);
+      float f = biased<T>(v.v[e], kbv, has_kb, cbv, has_cb);
       s += f;
       ss += f * f;
     }
@@ -132,15 +138,17 @@ __device__ __forceinline__ void group_stats(const uint16_t* __restrict__ chunk, 
 template <typename T, bool ACT, bool TOKENS>
 __global__ void __launch_bounds__(GN_THREADS)
 k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
-            const uint16_t* __restrict__ chan_bias, uint16_t* __restrict__ out, int C, int HW, int G, float eps) {
+            const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias, uint16_t* __restrict__ out,
+            int C, int HW, int G, float eps) {
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const int64_t len = (int64_t)cpg * HW;
   const uint16_t* chunk = x + ((int64_t)n * C + (int64_t)g * cpg) * HW;
   const uint16_t* cb = chan_bias ? chan_bias + (int64_t)n * C + (int64_t)g * cpg : nullptr;
-  const bool has_cb = cb != nullptr;
+  const uint16_t* kb = conv_bias ? conv_bias + (int64_t)g * cpg : nullptr;
+  const bool has_cb = cb != nullptr, has_kb = kb != nullptr;
   float mean, rstd;
-  group_stats<T>(chunk, len, HW, cb, eps, mean, rstd);
+  group_stats<T>(chunk, len, HW, kb, cb, eps, mean, rstd);
   if (!TOKENS) {
     uint16_t* dst = out + ((int64_t)n * C + (int64_t)g * cpg) * HW;
     for (int64_t i = (int64_t)threadIdx.x * 8; i < len; i += GN_THREADS * 8) {
@@ -149,10 +157,11 @@ k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
       float a = rstd * T::to_f32(gamma[c]);
       float b = fmaf(-a, mean, T::to_f32(beta[c]));
       const float cbv = has_cb ? T::to_f32(cb[cl]) : 0.f;
+      const float kbv = has_kb ? T::to_f32(kb[cl]) : 0.f;
       U16x8 v = *reinterpret_cast<const U16x8*>(chunk + i), o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(v.v[e], cbv, has_cb), b)));  // torch rounds the norm output first
+        float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(v.v[e], kbv, has_kb, cbv, has_cb), b)));  // torch rounds the norm output first
         o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
       }
       *reinterpret_cast<U16x8*>(dst + i) = o;
@@ -170,7 +179,8 @@ k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
           float a = rstd * T::to_f32(gamma[c]);
           float b = fmaf(-a, mean, T::to_f32(beta[c]));
           const float cbv = has_cb ? T::to_f32(cb[cc + e]) : 0.f;
-          float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(chunk[(int64_t)(cc + e) * HW + p], cbv, has_cb), b)));
+          const float kbv = has_kb ? T::to_f32(kb[cc + e]) : 0.f;
+          float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(chunk[(int64_t)(cc + e) * HW + p], kbv, has_kb, cbv, has_cb), b)));
           o4[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
         }
         uint2 pk;
@@ -459,6 +469,29 @@ k_tokens_add_nchw(const uint16_t* __restrict__ x, const uint16_t* __restrict__ t
   }
 }
 
+// ---- out[n,c,p] = round16(res[n,c,p] (+ rb[c])) + round16(h[n,c,p] + hb[c]) : ResnetBlock2D's closing add ------------
+// with the biases of conv2 (hb) and of the 1x1 shortcut convolution (rb) folded in.  torch / MIOpen ran this as one
+// broadcast bias-add kernel per convolution (elementwise_kernel_manual_unroll, 1.8 % of GPU time) plus the residual add;
+// every intermediate is rounded to 16 bit exactly where those kernels rounded.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bias_residual_add(const uint16_t* __restrict__ h, const uint16_t* __restrict__ hb, const uint16_t* __restrict__ res,
+                    const uint16_t* __restrict__ rb, uint16_t* __restrict__ out, int C, int HW, int64_t total_vec) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total_vec; t += (int64_t)gridDim.x * 256) {
+    const int c = (int)((t * 8 / HW) % C);  // HW % 8 == 0: a vector never straddles channels
+    const float b1 = hb ? T::to_f32(hb[c]) : 0.f, b2 = rb ? T::to_f32(rb[c]) : 0.f;
+    U16x8 hv = *reinterpret_cast<const U16x8*>(h + t * 8), rv = *reinterpret_cast<const U16x8*>(res + t * 8), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = T::to_f32(hv.v[e]), r = T::to_f32(rv.v[e]);
+      if (hb) a = T::to_f32(T::from_f32(a + b1));
+      if (rb) r = T::to_f32(T::from_f32(r + b2));
+      o.v[e] = T::from_f32(r + a);
+    }
+    *reinterpret_cast<U16x8*>(out + t * 8) = o;
+  }
+}
+
 inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -479,8 +512,8 @@ int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* strea
   return done();
 }
 
-int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* chan_bias, void* out, int dtype, int N,
-                 int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream) {
+int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+                 void* out, int dtype, int N, int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream) {
   if (N == 0) return 0;
   if (C % G != 0 || HW % 8 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
   if (tokens_out && (C / G) % 4 != 0) return (int)hipErrorInvalidValue;
@@ -488,7 +521,8 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void*
   hipStream_t s = (hipStream_t)stream;
 #define GN_LAUNCH(T, A, K) \
   k_groupnorm<T, A, K><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, \
-                                              (const uint16_t*)chan_bias, (uint16_t*)out, C, HW, G, eps)
+                                              (const uint16_t*)conv_bias, (const uint16_t*)chan_bias, (uint16_t*)out, C, \
+                                              HW, G, eps)
 #define GN_DISPATCH(T)                         \
   if (act_silu && !tokens_out) GN_LAUNCH(T, true, false);  \
   else if (act_silu) GN_LAUNCH(T, true, true);  \
@@ -582,6 +616,24 @@ int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void
   else if (dtype == ED_F16)
     k_add_layernorm<F16><<<grid, block, 0, s>>>((const uint16_t*)a, (const uint16_t*)b, (const uint16_t*)gamma,
                                                (const uint16_t*)beta, (uint16_t*)sum_out, (uint16_t*)out, M, D, eps);
+  else
+    return (int)hipErrorInvalidValue;
+  return done();
+}
+
+int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, const void* res_bias, void* out, int dtype,
+                         int N, int C, int HW, void* stream) {
+  if (N == 0) return 0;
+  if (HW % 8 != 0 || (((uintptr_t)h | (uintptr_t)res | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
+  int64_t total_vec = (int64_t)N * C * HW / 8;
+  int grid = (int)((total_vec + 255) / 256 < 8192 ? (total_vec + 255) / 256 : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ED_BF16)
+    k_bias_residual_add<BF16><<<grid, 256, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
+                                                   (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec);
+  else if (dtype == ED_F16)
+    k_bias_residual_add<F16><<<grid, 256, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
+                                                  (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec);
   else
     return (int)hipErrorInvalidValue;
   return done();

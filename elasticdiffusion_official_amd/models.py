@@ -40,16 +40,23 @@ def _fusable_nhwc(x):
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None):
-    """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout] of ``x`` (or of ``x + chan_bias[:, :, None, None]``: the
-    time-embedding add of ResnetBlock2D folded into the kernel).  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
+def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=None):
+    """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout] of ``x``, or of ``(x + conv_bias[c]) + chan_bias[n, c]``: the
+    bias of the (bias-free) convolution that produced x and the time-embedding add of ResnetBlock2D, folded into the
+    kernel.  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
     N, C, H, W = x.shape
     cpg = C // norm.num_groups
-    if chan_bias is not None and not (FUSED_TEMB_ADD and _fusable(x) and (H * W) % 8 == 0 and not tokens):
-        x, chan_bias = x + chan_bias[:, :, None, None], None
-    if chan_bias is not None:
+    if (chan_bias is not None or conv_bias is not None) and not (
+            FUSED_TEMB_ADD and _fusable(x) and (H * W) % 8 == 0 and not tokens):
+        if conv_bias is not None:
+            x = x + conv_bias[None, :, None, None]
+        if chan_bias is not None:
+            x = x + chan_bias[:, :, None, None]
+        chan_bias = conv_bias = None
+    if chan_bias is not None or conv_bias is not None:
         from . import ops
-        return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, chan_bias=chan_bias.contiguous())
+        return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu,
+                             chan_bias=None if chan_bias is None else chan_bias.contiguous(), conv_bias=conv_bias)
     if _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8:
         from . import ops
         y = ops.groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
@@ -65,6 +72,7 @@ def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None):
 
 FUSED_LAYERNORM = True
 FUSED_TEMB_ADD = True      # ResnetBlock2D: h + temb folded into norm2 (ed_groupnorm chan_bias)
+FUSED_CONV_BIAS = True     # ResnetBlock2D: bias-free convolutions, biases folded into norm2 / the closing residual add
 FUSED_ADD_LAYERNORM = True  # BasicTransformerBlock: residual add + next LayerNorm in one kernel (ed_add_layernorm)
 FUSED_TOKENS_ADD = True     # Transformer2DModel: tokens -> NCHW + residual in one kernel (ed_tokens_add_nchw)
 FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit) instead of SDPA / AOTriton
@@ -82,7 +90,8 @@ def fused_unet_entry_points():
     on = [("ed_groupnorm", FUSED_KERNELS), ("ed_geglu", FUSED_KERNELS), ("ed_layernorm", FUSED_KERNELS and FUSED_LAYERNORM),
           ("ed_flash_attention", FUSED_KERNELS and FLASH_ATTENTION),
           ("ed_add_layernorm", FUSED_KERNELS and FUSED_ADD_LAYERNORM),
-          ("ed_tokens_add_nchw", FUSED_KERNELS and FUSED_TOKENS_ADD)]
+          ("ed_tokens_add_nchw", FUSED_KERNELS and FUSED_TOKENS_ADD),
+          ("ed_bias_residual_add", FUSED_KERNELS and FUSED_CONV_BIAS and FUSED_TEMB_ADD)]
     return {n for n, flag in on if flag}
 
 
@@ -149,10 +158,20 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(group_norm_act(self.norm1, x, silu=True))
         tb = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
-        a = group_norm_act(self.norm2, h, silu=True, chan_bias=tb)  # GroupNorm(h + temb) (+SiLU)
         sc = self.conv_shortcut
+        if FUSED_CONV_BIAS and FUSED_TEMB_ADD and _fusable(x) and (x.shape[2] * x.shape[3]) % 8 == 0:
+            # MIOpen adds a convolution's bias with a separate broadcast kernel: run the convolutions bias-free and fold
+            # conv1's bias (+ temb) into norm2's passes, conv2's and the shortcut's into the closing residual add
+            from . import ops
+            h = F.conv2d(group_norm_act(self.norm1, x, silu=True), self.conv1.weight, None, padding=1)
+            a = group_norm_act(self.norm2, h, silu=True, chan_bias=tb, conv_bias=self.conv1.bias)
+            h = F.conv2d(a, self.conv2.weight, None, padding=1)
+            if sc is None:
+                return ops.bias_residual_add(h, self.conv2.bias, x)
+            return ops.bias_residual_add(h, self.conv2.bias, F.conv2d(x, sc.weight, None), sc.bias)
+        h = self.conv1(group_norm_act(self.norm1, x, silu=True))
+        a = group_norm_act(self.norm2, h, silu=True, chan_bias=tb)  # GroupNorm(h + temb) (+SiLU)
         if sc is not None and SHORTCUT_AS_GEMM and _fusable(x):
             # out = W_sc x + (conv2(a) + b_conv2 + b_sc): the shortcut bias rides on conv2's bias, the residual sum is
             # the GEMM's C operand

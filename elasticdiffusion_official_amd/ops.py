@@ -154,6 +154,62 @@ def pick_assemble(latent, idx, src_row, src_col, out, h, w, off_y=0, off_x=0, fr
     return out
 
 
+def assemble_rows(latent, idx, src_row, src_col, g_rows, h, w, g_off_y, g_off_x, gframe, low, v_rows, win_y0, win_x0, Sh,
+                  Sw, v_off_y, v_off_x, vframe):
+    """pick_assemble + gather_views in one launch (see ed_assemble_rows): g_rows [(K*2*B),C,gPH,gPW] and v_rows
+    [(V*B),C,vPH,vPW] are the two parts of one fused model batch (usually slices of one tensor)."""
+    B, C, H, W = latent.shape
+    K, V = idx.shape[0], win_y0.numel()
+    gr, C2, gPH, gPW = g_rows.shape
+    vr, C3, vPH, vPW = v_rows.shape
+    assert gr == K * 2 * B and vr == V * B and C2 == C == C3 and idx.shape[1] == h * w and g_rows.dtype == v_rows.dtype
+    assert src_row.numel() == 2 * h and src_col.numel() == 2 * w and win_x0.numel() == V
+    assert g_off_y + h <= gPH and g_off_x + w <= gPW and v_off_y + Sh <= vPH and v_off_x + Sw <= vPW
+    if gframe is not None:
+        assert tuple(gframe.shape) == (C, gPH, gPW)
+    if vframe is not None:
+        assert tuple(vframe.shape) == (C, vPH, vPW)
+    if low is not None:
+        assert tuple(low.shape) == (K, B, C, h, w)
+    _call("ed_assemble_rows", _dev(latent, torch.float32, "latent"), B, C, H, W, _dev(idx, torch.uint8, "idx"),
+          _dev(src_row, torch.int32), _dev(src_col, torch.int32), _opt(gframe, torch.float32, "gframe"),
+          _dev(g_rows, None, "g_rows"), _opt(low, torch.float32, "low"), K, h, w, gPH, gPW, g_off_y, g_off_x,
+          _dev(win_y0, torch.int32), _dev(win_x0, torch.int32), _opt(vframe, torch.float32, "vframe"),
+          _dev(v_rows, None, "v_rows"), V, Sh, Sw, vPH, vPW, v_off_y, v_off_x, _code(g_rows, "g_rows"), _stream())
+
+
+def phase_epilogue(g_out, v_out, x, stamp, pick_tables, view_tables, n_col_blocks, g_off, K, h, w, g, coef, prev, x0,
+                   low_dir=None, uncond_last=None, direction=None, local=None, x_next=None, low_latent=None,
+                   rrg_norm=0.0, rrg_weight=0.0):
+    """unpad_direction + fill_directions + scatter_centres + cfg_ddim_step (+ rrg_update when ``x_next`` is given) in
+    one launch (see ed_phase_epilogue).  pick_tables = (inv_row, inv_col, up_row, up_col, down_row, down_col);
+    view_tables = (row_blk, row_src, col_blk, col_src); coef = DDIMSchedule.step_coefficients(t)."""
+    B, C, H, W = x.shape
+    gr, C2, gPH, gPW = g_out.shape
+    vr, C3, vPH, vPW = v_out.shape
+    assert gr == K * 2 * B and C2 == C == C3 and vr % B == 0 and g_out.dtype == v_out.dtype
+    assert tuple(stamp.shape) == (h * w, 4) and tuple(prev.shape) == tuple(x.shape) == tuple(x0.shape)
+    inv_row, inv_col, up_row, up_col, down_row, down_col = pick_tables
+    assert inv_row.numel() == 2 * H and inv_col.numel() == 2 * W and up_row.numel() == H and up_col.numel() == W
+    assert down_row.numel() == h and down_col.numel() == w
+    row_blk, row_src, col_blk, col_src = view_tables
+    assert row_blk.numel() == H * 2 == row_src.numel() and col_blk.numel() == W * 2 == col_src.numel()
+    for t_, shp in ((low_dir, (B, C, h, w)), (uncond_last, (B, C, h, w)), (low_latent, (B, C, h, w)),
+                    (direction, (B, C, H, W)), (local, (B, C, H, W)), (x_next, (B, C, H, W))):
+        assert t_ is None or tuple(t_.shape) == shp
+    if x_next is not None and low_latent is None:
+        _reject("phase_epilogue: x_next (fused RRG) needs low_latent")
+    f32 = torch.float32
+    _call("ed_phase_epilogue", _dev(g_out, None, "g_out"), _dev(v_out, None, "v_out"), _code(g_out, "g_out"),
+          _dev(x, f32, "x"), _dev(stamp, torch.int8, "stamp"), *(_dev(t_, torch.int32) for t_ in pick_tables),
+          *(_dev(t_, torch.int32) for t_ in view_tables), _opt(low_latent, f32, "low_latent"), _dev(prev, f32, "prev"),
+          _dev(x0, f32, "x0"), _opt(x_next, f32, "x_next"), _opt(low_dir, f32, "low_dir"),
+          _opt(uncond_last, f32, "uncond_last"), _opt(direction, f32, "direction"), _opt(local, f32, "local"),
+          K, B, C, H, W, h, w, gPH, gPW, g_off[0], g_off[1], vPH, vPW, n_col_blocks, float(g), *(float(c) for c in coef),
+          float(rrg_norm), float(rrg_weight), _stream())
+    return prev, x0
+
+
 def unpad_direction(unet_out, dirs, uncond_last, off_y=0, off_x=0):
     """unet_out [(K*2*B),C,PH,PW] -> dirs f32 [K,B,C,h,w] (= cond - uncond), uncond_last f32 [B,C,h,w]."""
     K, B, C, h, w = dirs.shape
@@ -266,16 +322,20 @@ def geglu(x2, inner):
     return out
 
 
-def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False, chan_bias=None):
+def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False, chan_bias=None, conv_bias=None):
     """x [N,C,H,W] NCHW 16-bit -> GroupNorm(+SiLU) as [N,C,H,W], or [N,H*W,C] when ``tokens``.
-    ``chan_bias`` [N,C] (optional): normalise round16(x + chan_bias[:, :, None, None]) instead of x."""
+    ``conv_bias`` [C] / ``chan_bias`` [N,C] (optional): normalise round16(round16(x + conv_bias) + chan_bias) instead of
+    x (each add only when given) -- see ed_groupnorm."""
     N, C, H, W = x.shape
     if chan_bias is not None:
         assert tuple(chan_bias.shape) == (N, C)
+    if conv_bias is not None:
+        assert tuple(conv_bias.shape) == (C,)
     out = torch.empty((N, H * W, C) if tokens else (N, C, H, W), dtype=x.dtype, device=x.device)
     TIMER.note_work("ed_groupnorm", nbytes=3.0 * x.numel() * x.element_size())  # statistics pass + apply pass + write
     _call("ed_groupnorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
-          _opt(chan_bias, x.dtype, "chan_bias"), _dev(out, None, "out"), _code(x, "x"), N, C, H * W, groups, float(eps),
+          _opt(conv_bias, x.dtype, "conv_bias"), _opt(chan_bias, x.dtype, "chan_bias"), _dev(out, None, "out"),
+          _code(x, "x"), N, C, H * W, groups, float(eps),
           int(silu), int(tokens), _stream())
     return out
 
@@ -315,6 +375,17 @@ def add_layernorm(a, b, gamma, beta, eps):
           _dev(beta, a.dtype, "beta"), _dev(s, None, "sum"), _dev(out, None, "out"), _code(a, "a"), a.numel() // D, D,
           float(eps), _stream())
     return s, out
+
+
+def bias_residual_add(h, h_bias, res, res_bias=None):
+    """round16(res (+ res_bias[c])) + round16(h + h_bias[c]) for NCHW 16-bit tensors (ResnetBlock2D's closing add)."""
+    N, C, H, W = h.shape
+    assert res.shape == h.shape and res.dtype == h.dtype
+    out = torch.empty_like(h)
+    TIMER.note_work("ed_bias_residual_add", nbytes=3.0 * h.numel() * h.element_size())
+    _call("ed_bias_residual_add", _dev(h, None, "h"), _opt(h_bias, h.dtype, "h_bias"), _dev(res, None, "res"),
+          _opt(res_bias, h.dtype, "res_bias"), _dev(out, None, "out"), _code(h, "h"), N, C, H * W, _stream())
+    return out
 
 
 def tokens_add_nchw(x, tokens):

@@ -30,6 +30,11 @@ from .schedule import CosineScheduler, DDIMSchedule
 from .sharding import RowSharder
 
 
+# Fused latent-space glue: ed_assemble_rows before the model call and ed_phase_epilogue (+ RRG) after it -- 2 launches
+# per phase instead of 6-7.  False = the separate entry points (kept for A/B and for the per-kernel parity tests).
+FUSED_GLUE = True
+
+
 def _identity_progress(it):
     return it
 
@@ -362,10 +367,12 @@ class ElasticDiffusion(nn.Module):
                                 x_rows, text, pooled, cond_rows, t_dev)
 
     # ---- one estimation phase (ED:1016-1035 or ED:1043-1056) ---------------------------------------
-    def _phase_steps(self, P, x, ti, K, g, drop_p, emb, cond=None, direct=True):
+    def _phase_steps(self, P, x, ti, K, g, drop_p, emb, cond=None, direct=True, rrg_w=None, rrg_norm=0.0):
         """Generator: pre-model glue -> ``yield _ModelCall`` (receives the model output rows) -> post-model glue;
         returns (prev, x0, info).  ``direct``: assemble straight into the hipGraph's static input (one image in flight,
-        one rank); otherwise into a scratch batch the driver concatenates / the sharder slices."""
+        one rank); otherwise into a scratch batch the driver concatenates / the sharder slices.  ``rrg_w``: this is the
+        last phase of a timestep with Reduced-Resolution Guidance active -- with FUSED_GLUE the epilogue then also
+        produces info["x_next"] = prev + RRG term (ED:1061-1078)."""
         B, C = x.shape[:2]
         dev, mdt = self.device, self.model_dtype
         n_g, n_v = 2 * K * B, P.views.V * B
@@ -393,8 +400,12 @@ class ElasticDiffusion(nn.Module):
         else:
             g_rows = torch.empty(n_g, C, P.gpad.PH, P.gpad.PW, device=dev, dtype=mdt)
             v_rows = torch.empty(n_v, C, P.vpad.PH, P.vpad.PW, device=dev, dtype=mdt)
-        ops.pick_assemble(x, idx, P.src_row, P.src_col, g_rows, P.h, P.w, P.gpad.top, P.gpad.left, gframe, low)
-        ops.gather_views(x, v_rows, P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, vframe)
+        if FUSED_GLUE:
+            ops.assemble_rows(x, idx, P.src_row, P.src_col, g_rows, P.h, P.w, P.gpad.top, P.gpad.left, gframe, low,
+                              v_rows, P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, vframe)
+        else:
+            ops.pick_assemble(x, idx, P.src_row, P.src_col, g_rows, P.h, P.w, P.gpad.top, P.gpad.left, gframe, low)
+            ops.gather_views(x, v_rows, P.win_y0, P.win_x0, P.views.Sh, P.views.Sw, P.vpad.top, P.vpad.left, vframe)
         text, pooled = emb[K]
         t_dev = self._t_dev[ti]
         self.host_s["phase_total"] += time.perf_counter() - h0
@@ -408,19 +419,34 @@ class ElasticDiffusion(nn.Module):
             v_out = yield _ModelCall(v_rows, t_dev, text[n_g:].contiguous(), pooled[n_g:].contiguous(),
                                      None if cond is None else cond[K][1])
         h0 = time.perf_counter()
-        dirs = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
         uncond_last = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
-        ops.unpad_direction(g_out, dirs, uncond_last, P.gpad.top, P.gpad.left)
-        direction = torch.empty_like(x)
         low_dir = torch.empty(B, C, P.h, P.w, device=dev, dtype=torch.float32)
-        ops.fill_directions(dirs, stamp, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction, low_dir)
-        local = torch.empty_like(x)
-        ops.scatter_centres(v_out, local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src)
         prev, x0 = torch.empty_like(x), torch.empty_like(x)
-        ops.cfg_ddim_step(local, direction, x, prev, x0, np.float32(g), *self._step_coef[ti])
+        x_next, direction, local = None, None, None
+        if FUSED_GLUE:
+            keep = self.verbose  # the full-resolution direction / local score are only by-products for the image logs
+            direction = torch.empty_like(x) if keep else None
+            local = torch.empty_like(x) if keep else None
+            x_next = torch.empty_like(x) if rrg_w is not None else None
+            ops.phase_epilogue(g_out, v_out, x, stamp,
+                               (P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col),
+                               (P.row_blk, P.row_src, P.col_blk, P.col_src), P.views.n_col_blocks,
+                               (P.gpad.top, P.gpad.left), K, P.h, P.w, np.float32(g), self._step_coef[ti], prev, x0,
+                               low_dir=low_dir, uncond_last=uncond_last, direction=direction, local=local, x_next=x_next,
+                               low_latent=low[K - 1] if rrg_w is not None else None, rrg_norm=rrg_norm,
+                               rrg_weight=0.0 if rrg_w is None else np.float32(rrg_w))
+        else:
+            dirs = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
+            ops.unpad_direction(g_out, dirs, uncond_last, P.gpad.top, P.gpad.left)
+            direction = torch.empty_like(x)
+            ops.fill_directions(dirs, stamp, P.inv_row, P.inv_col, P.up_row, P.up_col, P.down_row, P.down_col, direction,
+                                low_dir)
+            local = torch.empty_like(x)
+            ops.scatter_centres(v_out, local, P.views.n_col_blocks, P.row_blk, P.row_src, P.col_blk, P.col_src)
+            ops.cfg_ddim_step(local, direction, x, prev, x0, np.float32(g), *self._step_coef[ti])
         self.host_s["phase_total"] += time.perf_counter() - h0
         info = {"low_latent": low[K - 1], "uncond_score": uncond_last, "low_direction": low_dir,
-                "direction": direction, "local": local, "init_low": low[0]}
+                "direction": direction, "local": local, "init_low": low[0], "x_next": x_next}
         return prev, x0, info
 
     def _drive(self, program):
@@ -550,15 +576,31 @@ class ElasticDiffusion(nn.Module):
             if self.controlnet is None:
                 raise ValueError("condition_image given but no controlnet was supplied")
             cond = self._condition_rows(P, condition_image, B, S.Ks)
+        logs = {"x0": [], "rrg_x0": [], "init_low": None, "embeds": (un, co, pun, pco)} if self.verbose else None
+        self._logs = logs
         for i, t in enumerate(progress(self._timesteps)):
-            prev, x0, info = yield from self._phase_steps(P, x, i, S.R + 1, S.guidance, S.drop_p, emb, cond, direct)
+            w_i = S.rrg(i)
+            rrg_w = w_i if w_i > 10 else None  # ED:1061-1062
+            two_phase = S.repaint and i < S.T - 1
+            prev, x0, info = yield from self._phase_steps(P, x, i, S.R + 1, S.guidance, S.drop_p, emb, cond, direct,
+                                                          None if two_phase else rrg_w, S.norm)
             cfg = S.guidance
-            if S.repaint and i < S.T - 1:  # ED:1038-1056
+            if two_phase:  # ED:1038-1056
                 x = self._undo(prev, i + 1)
                 cfg = S.guidance / 3
-                prev, x0, info = yield from self._phase_steps(P, x, i, 1, cfg, S.drop_p, emb, cond, direct)
-            w_i = S.rrg(i)
-            if w_i > 10:  # ED:1061-1078
+                prev, x0, info = yield from self._phase_steps(P, x, i, 1, cfg, S.drop_p, emb, cond, direct, rrg_w, S.norm)
+            if logs is not None:  # verbose image logs (ED:1023-1024, 1058-1059, 1073-1076)
+                if logs["init_low"] is None:
+                    logs["init_low"] = info["init_low"].clone()
+                if i % self.log_freq == 0:
+                    logs["x0"].append(x0.clone())
+                    if rrg_w is not None:  # the reduced-resolution x0 the guidance pulls towards (ED:909-921)
+                        sb, sa = self._step_coef[i][0], self._step_coef[i][1]
+                        eps = info["uncond_score"] + np.float32(cfg) * info["low_direction"]
+                        logs["rrg_x0"].append((info["low_latent"] - np.float32(sb) * eps) / np.float32(sa))
+            if info["x_next"] is not None:  # RRG already applied inside the fused epilogue
+                x = info["x_next"]
+            elif rrg_w is not None:  # ED:1061-1078
                 sb, sa = self._step_coef[i][0], self._step_coef[i][1]
                 nxt = torch.empty_like(prev)
                 ops.rrg_update(prev, x0, info["low_latent"], info["uncond_score"], info["low_direction"], P.up_row,
@@ -661,6 +703,78 @@ class ElasticDiffusion(nn.Module):
         self._mark("loop_done")
         return results
 
+    @_on_own_device
+    @torch.no_grad()
+    def generate(self, latent, text_embeds, add_text_embeds, guidance_scale=7.5):
+        """ED:761-796: plain CFG + DDIM generation of ``latent`` (B,C,h,w; the reference calls it on the initial
+        reduced-resolution latent for its ``verbose`` image log) over the scheduler's current timesteps.
+        ``text_embeds`` / ``add_text_embeds`` = cat([uncond, cond]) like the reference's.  A latent smaller than the
+        model's native size is padded with the noised-background frames (ED:404-411).
+        -> (PIL image of the first sample, {"inter_x0": [pred_original_sample every log_freq steps]})"""
+        dev, mdt = self.device, self.model_dtype
+        x = latent.to(dev, torch.float32).contiguous()
+        B, C, h, w = x.shape
+        if self.scheduler.timesteps is None:
+            raise RuntimeError("generate(): call scheduler.set_timesteps / generate_image first (ED:776 iterates them)")
+        ts = list(self.scheduler.timesteps)
+        pad = geometry.PadPlan(h, w, self.model_size)
+        frames = self._strip_frames(pad, ts, C)
+        xl = self.sd_version.startswith("XL")
+        text = text_embeds.to(dev, mdt).contiguous()
+        pooled = add_text_embeds.to(dev, mdt).contiguous() if xl else text
+        if self.default_size is None:
+            self.default_size = (4 * h * self.vae_scale_factor, 4 * w * self.vae_scale_factor)
+        d0, d1 = self.default_size
+        self._time_ids.copy_(torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32))
+        self._runner.new_image()
+        inter = []
+        for i, t in enumerate(ts):
+            if pad.padded:  # the reference re-seeds the global generators once per pad strip (ED:359)
+                host_rng.replay_strip_reseeds(len(pad.strips))
+            rows = torch.empty(2 * B, C, pad.PH, pad.PW, device=dev, dtype=mdt)
+            if frames is not None:
+                rows.copy_(frames[i].to(mdt).expand(2 * B, -1, -1, -1))
+            rows[:, :, pad.top:pad.top + h, pad.left:pad.left + w] = torch.cat([x, x]).to(mdt)
+            out = self._run_model(rows, torch.as_tensor(t, device=dev), text, pooled)
+            out = out[:, :, pad.top:pad.top + h, pad.left:pad.left + w].float()
+            uncond, cnd = out[:B].contiguous(), out[B:].contiguous()
+            prev, x0 = torch.empty_like(x), torch.empty_like(x)
+            ops.cfg_ddim_step(uncond, (cnd - uncond).contiguous(), x, prev, x0, np.float32(guidance_scale),
+                              *self.scheduler.step_coefficients(t))
+            x = prev
+            if i % self.log_freq == 0:
+                inter.append(x0.cpu())
+        return self._to_pil(self.decode_latents(x))[0], {"inter_x0": inter}
+
+    @staticmethod
+    def _to_pil(imgs):
+        from PIL import Image
+        arr = imgs.mul(255).byte().permute(0, 2, 3, 1).cpu().numpy()  # what ToPILImage does for float CHW (ED:1125)
+        return [Image.fromarray(a) for a in arr]
+
+    def _image_log(self, decode_fn, guidance_scale):
+        """ED:1092-1118: the ``verbose`` image log of the last single-image run (grids via make_grid's defaults)."""
+        logs, image_log = getattr(self, "_logs", None), {}
+        if not logs:
+            return image_log
+
+        def grid_of(latents):
+            dec = torch.cat([decode_fn(z[k:k + 1]) for z in latents for k in range(len(z))])
+            return self._to_pil(_make_grid(dec.clamp(0, 1))[None])[0]
+
+        if logs["init_low"] is not None:
+            un, co, pun, pco = logs["embeds"]
+            image_log["global_img"], info = self.generate(logs["init_low"], torch.cat([un, co]), torch.cat([pun, pco]),
+                                                          guidance_scale=guidance_scale)
+            if info["inter_x0"]:
+                image_log["global_img_inter_x0_imgs"] = grid_of([z.to(self.device) for z in info["inter_x0"]])
+        if logs["x0"]:
+            image_log["intermediate_x0_imgs"] = grid_of(logs["x0"])
+        image_log["intermediate_cascade_x0_imgs"] = {}
+        if logs["rrg_x0"]:
+            image_log["intermediate_cascade_x0_imgs"]["rrg"] = grid_of(logs["rrg_x0"])
+        return image_log
+
     # ---- decode (ED:267-310) -----------------------------------------------------------------------
     @_on_own_device
     @torch.no_grad()
@@ -707,15 +821,14 @@ class ElasticDiffusion(nn.Module):
                                   cosine_scale, repaint_sampling, progress, condition_image,
                                   controlnet_conditioning_scale)
         dec = self.tiled_decode if tiled_decoder else self.decode_latents
+        image_log = self._image_log(dec, guidance_scale) if self.verbose else {}  # ED:1092-1118 (before the final decode)
         imgs = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])  # decode_bs = 1 (ED:1090, 1121)
         self._mark("decode_done")
         if grid:
             imgs = _make_grid(imgs)[None]  # ED:1124: torchvision make_grid(imgs, nrow=8, padding=2, pad_value=0)
         if output_type == "pt":
-            return imgs, {}
-        from PIL import Image
-        arr = imgs.mul(255).byte().permute(0, 2, 3, 1).cpu().numpy()  # what ToPILImage does for float CHW (ED:1125)
-        return [Image.fromarray(a) for a in arr], {}
+            return imgs, image_log
+        return self._to_pil(imgs), image_log
 
 
 class ElasticDiffusionControlNet(ElasticDiffusion):

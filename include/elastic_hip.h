@@ -185,12 +185,23 @@ int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* strea
  * ed_groupnorm -- GroupNorm over NCHW 16-bit activations with optional fused SiLU (ResnetBlock2D norm1/norm2,
  * conv_norm_out) and optional [N,HW,C] token-layout output (Transformer2DModel.norm + the permute that follows).
  *   x dtype [N,C,HW] (NCHW contiguous), gamma/beta dtype [C], out dtype [N,C,HW] or [N,HW,C];
- *   chan_bias dtype [N,C] or NULL: when given, the tensor that is normalised is round16(x + chan_bias[n,c]) -- the
- *   time-embedding add `h + temb[:, :, None, None]` that precedes norm2 in ResnetBlock2D, folded into both passes;
+ *   conv_bias dtype [C] or NULL, chan_bias dtype [N,C] or NULL: when given, the tensor that is normalised is
+ *   round16(round16(x + conv_bias[c]) + chan_bias[n,c]) -- the bias of the convolution that produced x (run bias-free:
+ *   MIOpen would add it in a separate broadcast kernel) and the time-embedding add `h + temb[:, :, None, None]` that
+ *   precedes norm2 in ResnetBlock2D, folded into both passes with the roundings of the kernels they replace;
  *   HW % 8 == 0, C % G == 0 (and (C/G) % 4 == 0 for tokens_out); dtype = ED_F16 | ED_BF16.
  */
-int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* chan_bias, void* out, int dtype, int N,
-                 int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream);
+int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+                 void* out, int dtype, int N, int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream);
+
+/*
+ * ed_bias_residual_add -- ResnetBlock2D's closing add with the convolution biases folded in:
+ *   out[n,c,p] = round16(res[n,c,p] (+ res_bias[c])) + round16(h[n,c,p] + h_bias[c])
+ * h = conv2 output (bias-free), res = the block input or the bias-free 1x1 shortcut convolution; either bias may be NULL.
+ * [N,C,HW] 16-bit NCHW contiguous, HW % 8 == 0; dtype = ED_F16 | ED_BF16.
+ */
+int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, const void* res_bias, void* out, int dtype,
+                         int N, int C, int HW, void* stream);
 
 /*
  * ed_layernorm -- LayerNorm over the last dimension of [M, D] 16-bit activations (BasicTransformerBlock.norm1/2/3):
@@ -224,6 +235,38 @@ int ed_tokens_add_nchw(const void* x, const void* tokens, void* out, int dtype, 
 int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
                       int C, int HW, int G, float eps, int act_silu, void* stream);
 int64_t ed_groupnorm_nhwc_workspace(int N, int C, int HW, int G);
+
+/*
+ * ed_assemble_rows -- ed_pick_assemble + ed_gather_views in one launch: all rows of one fused model batch (K CFG pairs
+ * of the randomly picked reduced latent + V context crops).  Arguments as in those two entry points ("g" = the global /
+ * pick part with its own PH x PW and offsets, "v" = the view part); bit-identical to calling them one after the other.
+ */
+int ed_assemble_rows(const float* latent, int B, int C, int H, int W, const uint8_t* idx, const int32_t* src_row,
+                     const int32_t* src_col, const float* gframe, void* g_rows, float* low, int K, int h, int w, int gPH,
+                     int gPW, int g_off_y, int g_off_x, const int32_t* win_y0, const int32_t* win_x0,
+                     const float* vframe, void* v_rows, int V, int Sh, int Sw, int vPH, int vPW, int v_off_y, int v_off_x,
+                     int dtype, void* stream);
+
+/*
+ * ed_phase_epilogue -- everything between the model call and the next latent in one launch: ed_unpad_direction +
+ * ed_fill_directions + ed_scatter_centres + ed_cfg_ddim_step and, when x_next != NULL, ed_rrg_update
+ * (ED:429-443, 633-647 x K, 688, 852-861, 1031/1053 + scheduler.step, 886-940 + 1078).  Every output element is a gather
+ * over the model output rows, so no intermediate (dirs / direction / local) ever goes through HBM.  Bit-identical to the
+ * chain of separate entry points (same fp32 operation order).
+ *   g_out dtype [(K*2*B),C,gPH,gPW], v_out dtype [(V*B),C,vPH,vPW]: model output rows; x f32 [B,C,H,W] the latent the
+ *   phase started from; stamp / inv_* / up_* / down_* as ed_fill_directions; row_blk .. col_src as ed_scatter_centres;
+ *   prev, x0 f32 [B,C,H,W] (always written); low_dir, uncond_last f32 [B,C,h,w] and direction, local f32 [B,C,H,W] are
+ *   optional by-products (NULL = skip); x_next f32 [B,C,H,W] (optional) = prev + RRG term, needs low_latent f32 [B,C,h,w]
+ *   (the last picked reduced latent, ed_pick_assemble's `low[K-1]`), rrg_norm = 2/(C*H*W) and rrg_weight.
+ */
+int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const float* x, const int8_t* stamp,
+                      const int32_t* inv_row, const int32_t* inv_col, const int32_t* up_row, const int32_t* up_col,
+                      const int32_t* down_row, const int32_t* down_col, const int32_t* row_blk, const int32_t* row_src,
+                      const int32_t* col_blk, const int32_t* col_src, const float* low_latent, float* prev, float* x0,
+                      float* x_next, float* low_dir, float* uncond_last, float* direction, float* local, int K, int B,
+                      int C, int H, int W, int h, int w, int gPH, int gPW, int g_off_y, int g_off_x, int vPH, int vPW,
+                      int n_col_blocks, float g, float sqrt_beta_t, float sqrt_alpha_t, float sqrt_alpha_prev,
+                      float sqrt_1m_alpha_prev, float rrg_norm, float rrg_weight, void* stream);
 
 /*
  * ed_flash_attention -- fused attention forward of the UNet's transformer blocks (what diffusers' AttnProcessor2_0

@@ -62,6 +62,14 @@ def image_probe(img):
     return {"pool16": F.avg_pool2d(img, 16), "stride": img[..., 5::16, 11::16].contiguous(),
             "seam_rows": img[..., seams_r, :].contiguous(), "seam_cols": img[..., :, seams_c].contiguous()}
 
+# G11: the reference's plain CFG+DDIM ``generate`` (ED:761-796; used for its verbose "global_img" log) on a reduced
+# latent that needs padding (32x64 in a 64x64 model) and on one that does not
+G11_CASES = {
+    "gen_sd_pad_32x64": dict(sd="1.5", sample=64, h=32, w=64, steps=4, seed=21, guidance=7.5),
+    "gen_xl_64x128": dict(sd="XL1.0", sample=128, h=64, w=128, steps=3, seed=22, guidance=10.0),
+    "gen_sd_nopad_64x64": dict(sd="1.5", sample=64, h=64, w=64, steps=3, seed=23, guidance=5.0),
+}
+
 E2E_KW = dict(guidance_scale=10.0, new_p=0.3, rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0,
               repaint_sampling=True)
 

@@ -243,6 +243,32 @@ def g8_g10_end_to_end():
     print("g9_rng_trace.json", {k: len(v) for k, v in traces.items()})
 
 
+def g11_generate():
+    out = {}
+    for name, c in cases.G11_CASES.items():
+        pipe, ref, (un, pun, co, pco) = build(c["sd"], c["sample"])
+        pipe.log_freq = 1
+        pipe.default_size = (4 * 8 * c["h"], 4 * 8 * c["w"])
+        pipe.scheduler.set_timesteps(c["steps"])
+        pipe.seed_everything(c["seed"])
+        z = torch.randn(1, 4, c["h"], c["w"])
+        cap = {}
+        orig = pipe.decode_latents
+
+        def grab(lat, orig=orig, cap=cap):
+            cap["z"] = lat.clone()
+            return orig(lat)
+
+        pipe.decode_latents = grab
+        import tqdm as _tqdm  # the reference wraps the loop in tqdm (ED:767); silence it
+        ref.tqdm = lambda it, *a, **k: it
+        img, info = pipe.generate(z, torch.cat([un, co]), torch.cat([pun, pco]), guidance_scale=c["guidance"])
+        out[f"{name}/final"] = cap["z"]
+        out[f"{name}/inter_x0"] = torch.cat(info["inter_x0"])
+        out[f"{name}/rng_tail"] = torch.rand(4)
+    save("g11_generate", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g1_views()
@@ -250,3 +276,4 @@ if __name__ == "__main__":
     g3_to_g6_functions()
     g7_tiled_decode()
     g8_g10_end_to_end()
+    g11_generate()

@@ -382,7 +382,15 @@ def test_interleaved_images_equal_running_each_alone():
     from elasticdiffusion_official_amd import ElasticDiffusion
     kw = dict(height=512, width=1024, num_inference_steps=3, guidance_scale=10.0, resampling_steps=2, new_p=0.3,
               rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0, repaint_sampling=True)
-    pipe = ElasticDiffusion(DEV, "1.5", view_batch_size=4, unet=FakeUNet(64), vae=FakeVAE())
+    def embed(prompts):  # prompt-dependent deterministic embeddings of the fake model's width
+        out = []
+        for p in ([prompts] if isinstance(prompts, str) else prompts):
+            g = torch.Generator().manual_seed(sum(p.encode()) + 1)
+            out.append(torch.randn(1, 77, 32, generator=g))
+        e = torch.cat(out)
+        return e, e
+
+    pipe = ElasticDiffusion(DEV, "1.5", view_batch_size=4, unet=FakeUNet(64), vae=FakeVAE(), text_encoder=embed)
     jobs = [dict(prompts="a cat", negative_prompts="blurry", seed=11), dict(prompts="a dog", seed=12),
             dict(prompts=["two", "prompts"], seed=13)]
     alone = []
@@ -399,3 +407,156 @@ def test_interleaved_images_equal_running_each_alone():
         assert z.shape == want.shape
         assert rel_l2(z, want) < 1e-5, rel_l2(z, want)
     assert pipe._runner.stats()["eager"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused glue (ed_assemble_rows / ed_phase_epilogue) == the chain of separate entry points, bit for bit
+# ---------------------------------------------------------------------------------------------------
+FUSED_CASES = [  # Hl, Wl, h, w, model size d, patch
+    (64, 128, 32, 64, 64, None),      # cfg2: padded global rows
+    (128, 256, 64, 128, 128, None),   # cfg3
+    (256, 256, 128, 128, 128, None),  # cfg4: 16 views, no padding
+    (67, 97, 44, 64, 64, None),       # ragged: overlapping centres, fractional reduction, scalar (non-x4) paths
+    (32, 64, 32, 64, 64, None),       # views smaller than the model: padded VIEW rows too, separate row shapes
+    (96, 96, 64, 64, 64, 48),         # custom patch size
+]
+
+
+@pytest.mark.parametrize("Hl,Wl,h,w,d,patch", FUSED_CASES)
+@pytest.mark.parametrize("B,K,dtype", [(1, 4, torch.float32), (2, 1, torch.bfloat16), (1, 8, torch.float16)])
+def test_fused_glue_equals_separate_kernels(Hl, Wl, h, w, d, patch, B, K, dtype):
+    geometry, ops, schedule = _gpu_mods()
+    from elasticdiffusion_official_amd import host_rng
+    ws = patch if patch is not None else d // 2
+    pp, vp = geometry.PickPlan(Hl, Wl, h, w), geometry.ViewPlan(Hl, Wl, ws, ws, d - ws)
+    gpad, vpad = geometry.PadPlan(h, w, d), geometry.PadPlan(vp.Sh, vp.Sw, d)
+    g = torch.Generator().manual_seed(Hl * 131 + Wl + K)
+    x = torch.randn(B, 4, Hl, Wl, generator=g).to(DEV)
+    gframe = torch.randn(4, gpad.PH, gpad.PW, generator=g).to(DEV) if gpad.padded else None
+    vframe = torch.randn(4, vpad.PH, vpad.PW, generator=g).to(DEV) if vpad.padded else None
+    torch.manual_seed(17)
+    stamp = torch.empty(h * w, 4, dtype=torch.int8)
+    idx = host_rng.PickSampler(h * w).draw(K, 0.7, lambda: None, stamp=stamp).to(DEV)
+    stamp = stamp.to(DEV)
+    T = {k: dev_i32(getattr(pp, k)) for k in ("src_row", "src_col", "inv_row", "inv_col", "up_row", "up_col", "down_row", "down_col")}
+    wy, wx = dev_i32(vp.win_y0), dev_i32(vp.win_x0)
+    cover = tuple(dev_i32(a) for a in vp.cover_tables(vpad.top, vpad.left))
+    n_g, n_v = 2 * K * B, vp.V * B
+    # ---- assemble: separate vs fused ----
+    def rows():
+        return (torch.full((n_g, 4, gpad.PH, gpad.PW), 9.0, device=DEV, dtype=dtype),
+                torch.full((n_v, 4, vpad.PH, vpad.PW), 9.0, device=DEV, dtype=dtype))
+    g1, v1 = rows()
+    low1 = torch.empty(K, B, 4, h, w, device=DEV)
+    ops.pick_assemble(x, idx, T["src_row"], T["src_col"], g1, h, w, gpad.top, gpad.left, gframe, low1)
+    ops.gather_views(x, v1, wy, wx, vp.Sh, vp.Sw, vpad.top, vpad.left, vframe)
+    g2, v2 = rows()
+    low2 = torch.empty(K, B, 4, h, w, device=DEV)
+    ops.assemble_rows(x, idx, T["src_row"], T["src_col"], g2, h, w, gpad.top, gpad.left, gframe, low2, v2, wy, wx, vp.Sh,
+                      vp.Sw, vpad.top, vpad.left, vframe)
+    assert torch.equal(g1, g2) and torch.equal(v1, v2) and torch.equal(low1, low2)
+    # ---- epilogue: separate chain vs fused (model outputs with exact zeros so first-writer-wins is exercised) ----
+    g_out = torch.randn(n_g, 4, gpad.PH, gpad.PW, generator=g).to(dtype).to(DEV)
+    v_cpu = torch.randn(n_v, 4, vpad.PH, vpad.PW, generator=g)
+    v_cpu[torch.rand(v_cpu.shape, generator=g) < 0.2] = 0.0
+    v_out = v_cpu.to(dtype).to(DEV)
+    sch = schedule.DDIMSchedule()
+    ts = sch.set_timesteps(50)
+    coef = sch.step_coefficients(ts[7])
+    guidance, w_rrg, norm = np.float32(10.0 / 3), np.float32(437.53), np.float32(2.0 / (4 * Hl * Wl))
+    dirs = torch.empty(K, B, 4, h, w, device=DEV)
+    unc1, ldir1 = torch.empty(B, 4, h, w, device=DEV), torch.empty(B, 4, h, w, device=DEV)
+    direction1, local1 = torch.empty_like(x), torch.empty_like(x)
+    prev1, x01, nxt1 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    ops.unpad_direction(g_out, dirs, unc1, gpad.top, gpad.left)
+    ops.fill_directions(dirs, stamp, T["inv_row"], T["inv_col"], T["up_row"], T["up_col"], T["down_row"], T["down_col"],
+                        direction1, ldir1)
+    ops.scatter_centres(v_out, local1, vp.n_col_blocks, *cover)
+    ops.cfg_ddim_step(local1, direction1, x, prev1, x01, guidance, *coef)
+    ops.rrg_update(prev1, x01, low1[K - 1], unc1, ldir1, T["up_row"], T["up_col"], nxt1, guidance, coef[0], coef[1], norm, w_rrg)
+    out = {k: torch.full_like(x, 5.0) for k in ("prev", "x0", "x_next", "direction", "local")}
+    unc2, ldir2 = torch.full_like(unc1, 5.0), torch.full_like(ldir1, 5.0)
+    ops.phase_epilogue(g_out, v_out, x, stamp, tuple(T[k] for k in ("inv_row", "inv_col", "up_row", "up_col", "down_row", "down_col")),
+                       cover, vp.n_col_blocks, (gpad.top, gpad.left), K, h, w, guidance, coef, out["prev"], out["x0"],
+                       low_dir=ldir2, uncond_last=unc2, direction=out["direction"], local=out["local"],
+                       x_next=out["x_next"], low_latent=low1[K - 1], rrg_norm=norm, rrg_weight=w_rrg)
+    for name, want in (("prev", prev1), ("x0", x01), ("x_next", nxt1), ("direction", direction1), ("local", local1)):
+        assert torch.equal(out[name], want), name
+    assert torch.equal(unc2, unc1) and torch.equal(ldir2, ldir1)
+    # optional outputs may be omitted
+    p3, z3 = torch.empty_like(x), torch.empty_like(x)
+    ops.phase_epilogue(g_out, v_out, x, stamp, tuple(T[k] for k in ("inv_row", "inv_col", "up_row", "up_col", "down_row", "down_col")),
+                       cover, vp.n_col_blocks, (gpad.top, gpad.left), K, h, w, guidance, coef, p3, z3)
+    assert torch.equal(p3, prev1) and torch.equal(z3, x01)
+
+
+@pytest.mark.parametrize("name", ["cfg2_sd_512x1024", "cfg3_xl_1024x2048", "overlap_536x776"])
+def test_end_to_end_with_separate_glue_kernels(golden_dir, name):
+    """The un-fused glue path (FUSED_GLUE = False) still reproduces the reference goldens, and the fused default gives
+    the SAME latents bit for bit (same fp32 operation order)."""
+    from elasticdiffusion_official_amd import ElasticDiffusion, pipeline
+    c = cases.E2E_CASES[name]
+    g = np.load(os.path.join(golden_dir, "g8_end_to_end.npz"))
+    xl = c["sd"].startswith("XL")
+    kw = dict(cases.E2E_KW)
+    kw.update(c.get("kw", {}))
+    lat = {}
+    for fused in (False, True):
+        pipeline.FUSED_GLUE = fused
+        try:
+            pipe = ElasticDiffusion(DEV, c["sd"], view_batch_size=c["vbs"], unet=FakeUNet(c["sample"], xl=xl), vae=FakeVAE(),
+                                    text_encoder=_embed_fn(xl))
+            pipe.seed_everything(c["seed"])
+            lat[fused] = pipe.generate_latents("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                                               resampling_steps=c["R"], **kw).cpu()
+        finally:
+            pipeline.FUSED_GLUE = True
+    assert rel_l2(lat[False], torch.from_numpy(g[f"{name}/latent"])) < 1e-4
+    assert torch.equal(lat[False], lat[True])
+
+
+# ---------------------------------------------------------------------------------------------------
+# generate() and the verbose image logs (ED:761-796, 1092-1118)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.G11_CASES))
+def test_generate_vs_reference_golden(golden_dir, name):
+    """The reference's plain CFG + DDIM ``generate`` (its verbose "global_img"), incl. the noised-background padding of
+    a latent smaller than the model and the per-strip reseed side effects on the host generators."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    c = cases.G11_CASES[name]
+    g = np.load(os.path.join(golden_dir, "g11_generate.npz"))
+    xl = c["sd"].startswith("XL")
+    (un, pun), (co, pco) = synthetic_text_embeds(1, xl=xl)
+    pipe = ElasticDiffusion(DEV, c["sd"], log_freq=1, unet=FakeUNet(c["sample"], xl=xl), vae=FakeVAE())
+    pipe.default_size = (4 * 8 * c["h"], 4 * 8 * c["w"])
+    pipe.scheduler.set_timesteps(c["steps"])
+    pipe.seed_everything(c["seed"])
+    z = torch.randn(1, 4, c["h"], c["w"])
+    seen = {}
+    dec = pipe.decode_latents
+    pipe.decode_latents = lambda lat: (seen.__setitem__("z", lat.clone()), dec(lat))[1]
+    img, info = pipe.generate(z, torch.cat([un, co]), torch.cat([pun, pco]), guidance_scale=c["guidance"])
+    tail = torch.rand(4)
+    assert img.size == (c["w"] * 8, c["h"] * 8)
+    assert rel_l2(seen["z"], torch.from_numpy(g[f"{name}/final"])) < 1e-4
+    assert rel_l2(torch.cat(info["inter_x0"]), torch.from_numpy(g[f"{name}/inter_x0"])) < 1e-4
+    np.testing.assert_array_equal(tail.numpy(), g[f"{name}/rng_tail"])
+
+
+def test_verbose_image_log():
+    """verbose=True: the reference's image_log keys (ED:1092-1118), PIL grids of the right size; latents unchanged."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    kw = dict(height=512, width=1024, num_inference_steps=4, guidance_scale=10.0, resampling_steps=2, new_p=0.3,
+              rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0, repaint_sampling=True)
+    lat = {}
+    for verbose in (False, True):
+        pipe = ElasticDiffusion(DEV, "1.5", verbose=verbose, log_freq=2, view_batch_size=4, unet=FakeUNet(64), vae=FakeVAE(),
+                                text_encoder=_embed_fn(False))
+        pipe.seed_everything(3)
+        imgs, log = pipe.generate_image("p", "", **kw)
+        lat[verbose] = pipe.last_latents.clone()
+    assert torch.equal(lat[False], lat[True])
+    assert set(log) == {"global_img", "global_img_inter_x0_imgs", "intermediate_x0_imgs", "intermediate_cascade_x0_imgs"}
+    assert log["global_img"].size == (512, 256)                      # the reduced-resolution generation (32x64 latent)
+    assert log["intermediate_x0_imgs"].size == (2 * 1026 + 2, 516)  # 2 logged steps in make_grid's padded layout
+    assert set(log["intermediate_cascade_x0_imgs"]) == {"rrg"}

@@ -264,6 +264,24 @@ def test_groupnorm_with_channel_bias(dtype, N, C, H, W):
     got = ops.groupnorm(x, w, b, 32, 1e-5, silu=True, chan_bias=cb)
     want = ops.groupnorm(x + cb[:, :, None, None], w, b, 32, 1e-5, silu=True)
     assert torch.equal(got, want)
+    kb = torch.randn(C, device=DEV).to(dtype)  # + the producing convolution's bias, added (and rounded) first
+    got = ops.groupnorm(x, w, b, 32, 1e-5, silu=True, chan_bias=cb, conv_bias=kb)
+    want = ops.groupnorm((x + kb[None, :, None, None]) + cb[:, :, None, None], w, b, 32, 1e-5, silu=True)
+    assert torch.equal(got, want)
+    got = ops.groupnorm(x, w, b, 32, 1e-5, conv_bias=kb)
+    assert torch.equal(got, ops.groupnorm(x + kb[None, :, None, None], w, b, 32, 1e-5))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 1280, 8, 8), (1, 64, 2, 4)])
+def test_bias_residual_add(dtype, N, C, H, W):
+    from elasticdiffusion_official_amd import ops
+    h, res = (torch.randn(N, C, H, W, device=DEV).to(dtype) for _ in range(2))
+    hb, rb = (torch.randn(C, device=DEV).to(dtype) for _ in range(2))
+    bc = lambda v: v[None, :, None, None]
+    assert torch.equal(ops.bias_residual_add(h, hb, res), res + (h + bc(hb)))
+    assert torch.equal(ops.bias_residual_add(h, hb, res, rb), (res + bc(rb)) + (h + bc(hb)))
+    assert torch.equal(ops.bias_residual_add(h, None, res), res + h)
 
 
 def test_unet_round2_fusions_close():
@@ -275,7 +293,7 @@ def test_unet_round2_fusions_close():
     e = torch.randn(3, 77, 64, device=DEV, dtype=torch.bfloat16)
     kw = {"text_embeds": torch.randn(3, 32, device=DEV, dtype=torch.bfloat16), "time_ids": torch.zeros(3, 6, device=DEV)}
     t = torch.tensor(500, device=DEV)
-    names = ("FLASH_ATTENTION", "FUSED_QKV", "FUSED_ADD_LAYERNORM", "FUSED_TOKENS_ADD", "FUSED_TEMB_ADD")
+    names = ("FLASH_ATTENTION", "FUSED_QKV", "FUSED_ADD_LAYERNORM", "FUSED_TOKENS_ADD", "FUSED_TEMB_ADD", "FUSED_CONV_BIAS")
     saved = {n: getattr(M, n) for n in names}
     try:
         with torch.no_grad():

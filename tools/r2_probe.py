@@ -95,7 +95,7 @@ def inputs(cfg, B):
 
 
 def probe_unet(unet, cfg):
-    names = ("FLASH_ATTENTION", "FUSED_QKV", "FUSED_ADD_LAYERNORM", "FUSED_TOKENS_ADD", "FUSED_TEMB_ADD")
+    names = ("FLASH_ATTENTION", "FUSED_QKV", "FUSED_ADD_LAYERNORM", "FUSED_TOKENS_ADD", "FUSED_TEMB_ADD", "FUSED_CONV_BIAS")
     for B in (20, 6):
         x, e, kw, t = inputs(cfg, B)
 
