@@ -40,12 +40,13 @@ SIGNATURES = {
     "ed_tile_gather_pad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _vp],
     "ed_tile_accumulate_normalise": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "ed_geglu": [_vp, _vp, _i, _i64, _i, _vp],
-    "ed_groupnorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
-    "ed_bias_residual_add": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ed_groupnorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ed_groupnorm_workspace": [_i, _i, _i, _i],
+    "ed_bias_residual_add": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ed_add_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
     "ed_tokens_add_nchw": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ed_layernorm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
-    "ed_groupnorm_nhwc": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "ed_groupnorm_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc_workspace": [_i, _i, _i, _i],
     "ed_assemble_rows": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                          _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -83,7 +84,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the .so does not export what the header declares
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "ed_error_string" else
-                          ctypes.c_int64 if name == "ed_groupnorm_nhwc_workspace" else ctypes.c_int)
+                          ctypes.c_int64 if name.endswith("_workspace") else ctypes.c_int)
         if L.ed_version() != ABI_VERSION:
             raise RuntimeError(f"libelastic_hip.so ABI {L.ed_version()} != expected {ABI_VERSION}; rebuild")
         _LIB = L

@@ -193,6 +193,126 @@ k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
 }
 
 
+// ---- GroupNorm for LARGE groups: statistics and apply as two fully parallel launches ---------------------------------
+// One workgroup per (sample, group) leaves the chip under-filled when a group is hundreds of KB (SDXL level 1: 10-30
+// channels x 128 x 128): N*G = 640 workgroups walk 0.3-1 MB each, twice (measured 2.4 TB/s).  Here every group is cut
+// into `chunks` token ranges; k_gn_split_stats writes one Welford partial per (group, chunk), k_gn_split_apply merges the
+// partials of its group (a few dozen floats) and normalises its own range.  Same traffic (2 reads + 1 write), all of it
+// spread over thousands of workgroups.  Partials are merged in chunk order: deterministic.
+#define GNS_THREADS 256
+
+template <typename T>
+__global__ void __launch_bounds__(GNS_THREADS)
+k_gn_split_stats(const uint16_t* __restrict__ x, const uint16_t* __restrict__ conv_bias,
+                 const uint16_t* __restrict__ chan_bias, float* __restrict__ partial, int C, int HW, int G, int chunks,
+                 int span) {
+  const int ng = blockIdx.y, chunk = blockIdx.x;
+  const int n = ng / G, g = ng % G, cpg = C / G;
+  const uint16_t* base = x + ((int64_t)n * C + (int64_t)g * cpg) * HW;
+  const uint16_t* cb = chan_bias ? chan_bias + (int64_t)n * C + (int64_t)g * cpg : nullptr;
+  const uint16_t* kb = conv_bias ? conv_bias + (int64_t)g * cpg : nullptr;
+  const bool has_cb = cb != nullptr, has_kb = kb != nullptr;
+  const int p0 = chunk * span, p1 = min(HW, p0 + span);
+  const int vec_per_row = (p1 - p0) >> 3;  // span and HW are multiples of 8
+  float s = 0.f, ss = 0.f, cnt = 0.f;
+  for (int it = threadIdx.x; it < cpg * vec_per_row; it += GNS_THREADS) {
+    const int c = it / vec_per_row, pv = it - c * vec_per_row;
+    U16x8 v = *reinterpret_cast<const U16x8*>(base + (int64_t)c * HW + p0 + (pv << 3));
+    const float cbv = has_cb ? T::to_f32(cb[c]) : 0.f, kbv = has_kb ? T::to_f32(kb[c]) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = biased<T>(v.v[e], kbv, has_kb, cbv, has_cb);
+      s += f;
+      ss += f * f;
+    }
+    cnt += 8.f;
+  }
+  Welford w;
+  w.n = cnt;
+  w.mean = cnt > 0.f ? s / cnt : 0.f;
+  w.m2 = cnt > 0.f ? fmaxf(ss - s * w.mean, 0.f) : 0.f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Welford o;
+    o.n = __shfl_down(w.n, off, 64);
+    o.mean = __shfl_down(w.mean, off, 64);
+    o.m2 = __shfl_down(w.m2, off, 64);
+    w = merge(w, o);
+  }
+  __shared__ Welford part[GNS_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Welford t = part[0];
+    for (int k = 1; k < GNS_THREADS / 64; ++k) t = merge(t, part[k]);
+    float* dst = partial + ((int64_t)ng * chunks + chunk) * 3;
+    dst[0] = t.n, dst[1] = t.mean, dst[2] = t.m2;
+  }
+}
+
+template <typename T, bool ACT, bool TOKENS>
+__global__ void __launch_bounds__(GNS_THREADS)
+k_gn_split_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
+                 const float* __restrict__ partial, uint16_t* __restrict__ out, int C, int HW, int G, int chunks, int span,
+                 float eps) {
+  const int ng = blockIdx.y, chunk = blockIdx.x;
+  const int n = ng / G, g = ng % G, cpg = C / G;
+  __shared__ float sh_mean, sh_rstd;
+  if (threadIdx.x == 0) {
+    const float* src = partial + (int64_t)ng * chunks * 3;
+    Welford t = {src[0], src[1], src[2]};
+    for (int k = 1; k < chunks; ++k) t = merge(t, Welford{src[3 * k], src[3 * k + 1], src[3 * k + 2]});
+    sh_mean = t.mean;
+    sh_rstd = rsqrtf(t.m2 / t.n + eps);
+  }
+  __syncthreads();
+  const float mean = sh_mean, rstd = sh_rstd;
+  const uint16_t* base = x + ((int64_t)n * C + (int64_t)g * cpg) * HW;
+  const uint16_t* cb = chan_bias ? chan_bias + (int64_t)n * C + (int64_t)g * cpg : nullptr;
+  const uint16_t* kb = conv_bias ? conv_bias + (int64_t)g * cpg : nullptr;
+  const bool has_cb = cb != nullptr, has_kb = kb != nullptr;
+  const int p0 = chunk * span, p1 = min(HW, p0 + span);
+  if (!TOKENS) {
+    uint16_t* dst = out + ((int64_t)n * C + (int64_t)g * cpg) * HW;
+    const int vec_per_row = (p1 - p0) >> 3;
+    for (int it = threadIdx.x; it < cpg * vec_per_row; it += GNS_THREADS) {
+      const int cl = it / vec_per_row, pv = it - cl * vec_per_row, c = g * cpg + cl;
+      const int64_t off = (int64_t)cl * HW + p0 + (pv << 3);
+      const float a = rstd * T::to_f32(gamma[c]);
+      const float b = fmaf(-a, mean, T::to_f32(beta[c]));
+      const float cbv = has_cb ? T::to_f32(cb[cl]) : 0.f, kbv = has_kb ? T::to_f32(kb[cl]) : 0.f;
+      U16x8 v = *reinterpret_cast<const U16x8*>(base + off), o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(v.v[e], kbv, has_kb, cbv, has_cb), b)));
+        o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+      }
+      *reinterpret_cast<U16x8*>(dst + off) = o;
+    }
+  } else {
+    for (int p = p0 + threadIdx.x; p < p1; p += GNS_THREADS) {
+      uint16_t* row = out + ((int64_t)n * HW + p) * C + (int64_t)g * cpg;
+      for (int cc = 0; cc < cpg; cc += 4) {
+        uint16_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int c = g * cpg + cc + e;
+          float a = rstd * T::to_f32(gamma[c]);
+          float b = fmaf(-a, mean, T::to_f32(beta[c]));
+          const float cbv = has_cb ? T::to_f32(cb[cc + e]) : 0.f, kbv = has_kb ? T::to_f32(kb[cc + e]) : 0.f;
+          float y = T::to_f32(T::from_f32(fmaf(a, biased<T>(base[(int64_t)(cc + e) * HW + p], kbv, has_kb, cbv, has_cb), b)));
+          o4[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+        }
+        uint2 pk;
+        pk.x = (uint32_t)o4[0] | ((uint32_t)o4[1] << 16);
+        pk.y = (uint32_t)o4[2] | ((uint32_t)o4[3] << 16);
+        *reinterpret_cast<uint2*>(row + cc) = pk;
+      }
+    }
+  }
+}
+
 // ---- GroupNorm (+SiLU) over channels-last activations [N, HW, C] ------------------------------------
 // Three small launches: (1) per-block partial sums per group, (2) finalise mean / rstd in double, (3) vectorised apply.
 // Reads 2x, writes 1x -- same traffic as the NCHW kernel -- but every access is a full 16-byte channel vector, and the
@@ -201,7 +321,9 @@ k_groupnorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
 
 template <typename T>
 __global__ void __launch_bounds__(GNL_THREADS)
-k_gn_nhwc_partial(const uint16_t* __restrict__ x, float* __restrict__ partial, int C, int HW, int G, int rows_per_block) {
+k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ conv_bias,
+                  const uint16_t* __restrict__ chan_bias, float* __restrict__ partial, int C, int HW, int G,
+                  int rows_per_block) {
   // block (n, chunk): rows [chunk*rows_per_block, ...) of sample n; thread t walks (row, vec8) pairs with stride 256
   extern __shared__ float sh[];  // [G*2] group sums
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -211,6 +333,8 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, float* __restrict__ partial, i
   int r0 = chunk * rows_per_block;
   int r1 = min(HW, r0 + rows_per_block);
   const uint16_t* base = x + (int64_t)n * HW * C;
+  const uint16_t* cbn = chan_bias ? chan_bias + (int64_t)n * C : nullptr;
+  const bool has_cb = cbn != nullptr, has_kb = conv_bias != nullptr;
   int64_t total = (int64_t)(r1 - r0) * VC;
   // a thread's successive items advance by 256 vectors; when VC divides 256 (or vice versa) it keeps the same
   // channels, in general it does not, so sums are binned per item into at most two groups
@@ -235,9 +359,12 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, float* __restrict__ partial, i
       acc_s[0] = acc_s[1] = acc_q[0] = acc_q[1] = 0.f;
     }
     int split = (g0 + 1) * cpg - c0;  // channels [0, split) of this vector belong to g0, the rest to g0+1
+    U16x8 kbv, cbv;
+    if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
+    if (has_cb) cbv = *reinterpret_cast<const U16x8*>(cbn + c0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float f = T::to_f32(v.v[e]);
+      float f = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
       int k = e < split ? 0 : 1;
       acc_s[k] += f;
       acc_q[k] += f * f;
@@ -277,7 +404,9 @@ __global__ void k_gn_nhwc_finalize(const float* __restrict__ partial, float* __r
 template <typename T, bool ACT>
 __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
                 const float* __restrict__ stats, uint16_t* __restrict__ out, int C, int HW, int G, int64_t total_vec) {
+  const bool has_cb = chan_bias != nullptr, has_kb = conv_bias != nullptr;
   const int VC = C >> 3, cpg = C / G;
   for (int64_t t = (int64_t)blockIdx.x * GNL_THREADS + threadIdx.x; t < total_vec; t += (int64_t)gridDim.x * GNL_THREADS) {
     int vc = (int)(t % VC);
@@ -287,6 +416,9 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
     U16x8 v = *reinterpret_cast<const U16x8*>(x + t * 8);
     U16x8 gm = *reinterpret_cast<const U16x8*>(gamma + c0);
     U16x8 bt = *reinterpret_cast<const U16x8*>(beta + c0);
+    U16x8 kbv, cbv;
+    if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
+    if (has_cb) cbv = *reinterpret_cast<const U16x8*>(chan_bias + (int64_t)n * C + c0);
     U16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -294,7 +426,8 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
       float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
       float a = rstd * T::to_f32(gm.v[e]);
       float b = fmaf(-a, mean, T::to_f32(bt.v[e]));
-      float y = T::to_f32(T::from_f32(fmaf(a, T::to_f32(v.v[e]), b)));
+      float xin = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
+      float y = T::to_f32(T::from_f32(fmaf(a, xin, b)));
       o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
     }
     *reinterpret_cast<U16x8*>(out + t * 8) = o;
@@ -476,16 +609,24 @@ k_tokens_add_nchw(const uint16_t* __restrict__ x, const uint16_t* __restrict__ t
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_bias_residual_add(const uint16_t* __restrict__ h, const uint16_t* __restrict__ hb, const uint16_t* __restrict__ res,
-                    const uint16_t* __restrict__ rb, uint16_t* __restrict__ out, int C, int HW, int64_t total_vec) {
+                    const uint16_t* __restrict__ rb, uint16_t* __restrict__ out, int C, int HW, int64_t total_vec,
+                    int channels_last) {
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total_vec; t += (int64_t)gridDim.x * 256) {
-    const int c = (int)((t * 8 / HW) % C);  // HW % 8 == 0: a vector never straddles channels
-    const float b1 = hb ? T::to_f32(hb[c]) : 0.f, b2 = rb ? T::to_f32(rb[c]) : 0.f;
+    // NCHW: the 8 elements share one channel (HW % 8 == 0); channels-last: they are 8 consecutive channels (C % 8 == 0)
+    const int c = channels_last ? (int)((t * 8) % C) : (int)((t * 8 / HW) % C);
+    float b1[8], b2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ce = channels_last ? c + e : c;
+      b1[e] = hb ? T::to_f32(hb[ce]) : 0.f;
+      b2[e] = rb ? T::to_f32(rb[ce]) : 0.f;
+    }
     U16x8 hv = *reinterpret_cast<const U16x8*>(h + t * 8), rv = *reinterpret_cast<const U16x8*>(res + t * 8), o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = T::to_f32(hv.v[e]), r = T::to_f32(rv.v[e]);
-      if (hb) a = T::to_f32(T::from_f32(a + b1));
-      if (rb) r = T::to_f32(T::from_f32(r + b2));
+      if (hb) a = T::to_f32(T::from_f32(a + b1[e]));
+      if (rb) r = T::to_f32(T::from_f32(r + b2[e]));
       o.v[e] = T::from_f32(r + a);
     }
     *reinterpret_cast<U16x8*>(out + t * 8) = o;
@@ -512,13 +653,59 @@ int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* strea
   return done();
 }
 
+// groups of more than GN_SPLIT_MIN elements are cut into chunks of ~GN_SPLIT_SPAN elements (see k_gn_split_*)
+#define GN_SPLIT_MIN 65536
+#define GN_SPLIT_SPAN 32768
+static inline void gn_split_plan(int C, int HW, int G, int* chunks, int* span) {
+  int64_t len = (int64_t)(C / G) * HW;
+  int want = (int)((len + GN_SPLIT_SPAN - 1) / GN_SPLIT_SPAN);
+  int sp = ((HW + want - 1) / want + 7) & ~7;  // tokens per chunk, multiple of 8
+  *span = sp;
+  *chunks = (HW + sp - 1) / sp;
+}
+
+int64_t ed_groupnorm_workspace(int N, int C, int HW, int G) {
+  if (G <= 0 || C % G != 0 || (int64_t)(C / G) * HW <= GN_SPLIT_MIN) return 0;
+  int chunks, span;
+  gn_split_plan(C, HW, G, &chunks, &span);
+  return (int64_t)N * G * chunks * 3 * (int64_t)sizeof(float);
+}
+
 int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
-                 void* out, int dtype, int N, int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream) {
+                 void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
+                 int tokens_out, void* stream) {
   if (N == 0) return 0;
   if (C % G != 0 || HW % 8 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
   if (tokens_out && (C / G) % 4 != 0) return (int)hipErrorInvalidValue;
-  dim3 grid(N * G), block(GN_THREADS);
   hipStream_t s = (hipStream_t)stream;
+  if (workspace && (int64_t)(C / G) * HW > GN_SPLIT_MIN) {
+    int chunks, span;
+    gn_split_plan(C, HW, G, &chunks, &span);
+    if ((int64_t)N * G > 65535) return (int)hipErrorInvalidValue;
+    dim3 sgrid(chunks, N * G), sblock(GNS_THREADS);
+#define GNS_APPLY(T, A, K)                                                                                              \
+  k_gn_split_apply<T, A, K><<<sgrid, sblock, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, \
+                                                     (const uint16_t*)conv_bias, (const uint16_t*)chan_bias, workspace,  \
+                                                     (uint16_t*)out, C, HW, G, chunks, span, eps)
+#define GNS_RUN(T)                                                                                                      \
+  k_gn_split_stats<T><<<sgrid, sblock, 0, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                          \
+                                               (const uint16_t*)chan_bias, workspace, C, HW, G, chunks, span);           \
+  if (act_silu && !tokens_out) GNS_APPLY(T, true, false);                                                               \
+  else if (act_silu) GNS_APPLY(T, true, true);                                                                          \
+  else if (!tokens_out) GNS_APPLY(T, false, false);                                                                     \
+  else GNS_APPLY(T, false, true);
+    if (dtype == ED_BF16) {
+      GNS_RUN(BF16)
+    } else if (dtype == ED_F16) {
+      GNS_RUN(F16)
+    } else {
+      return (int)hipErrorInvalidValue;
+    }
+#undef GNS_RUN
+#undef GNS_APPLY
+    return done();
+  }
+  dim3 grid(N * G), block(GN_THREADS);
 #define GN_LAUNCH(T, A, K) \
   k_groupnorm<T, A, K><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta, \
                                               (const uint16_t*)conv_bias, (const uint16_t*)chan_bias, (uint16_t*)out, C, \
@@ -540,8 +727,9 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void*
   return done();
 }
 
-int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
-                      int C, int HW, int G, float eps, int act_silu, void* stream) {
+int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+                      void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
+                      void* stream) {
   if (N == 0) return 0;
   // C/G >= 8: an 8-channel vector then touches at most two groups (what the partial-sum kernel bins into)
   if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 ||
@@ -560,14 +748,17 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* 
   int grid3 = (int)((total_vec + GNL_THREADS - 1) / GNL_THREADS < 8192 ? (total_vec + GNL_THREADS - 1) / GNL_THREADS : 8192);
   int NG = N * G;
 #define GNL_RUN(T)                                                                                                     \
-  k_gn_nhwc_partial<T><<<grid1, GNL_THREADS, lds, s>>>((const uint16_t*)x, partial, C, HW, G, rows_per_block);         \
+  k_gn_nhwc_partial<T><<<grid1, GNL_THREADS, lds, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                \
+                                                       (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
   k_gn_nhwc_finalize<<<(NG + 127) / 128, 128, 0, s>>>(partial, stats, G, nchunks, (double)HW * (C / G), eps, NG);      \
   if (act_silu)                                                                                                        \
     k_gn_nhwc_apply<T, true><<<grid3, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
-                                                          (const uint16_t*)beta, stats, (uint16_t*)out, C, HW, G, total_vec); \
+                                                          (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
+                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, total_vec); \
   else                                                                                                                 \
     k_gn_nhwc_apply<T, false><<<grid3, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                \
-                                                           (const uint16_t*)beta, stats, (uint16_t*)out, C, HW, G, total_vec);
+                                                           (const uint16_t*)beta, (const uint16_t*)conv_bias,          \
+                                                           (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, total_vec);
   if (dtype == ED_BF16) {
     GNL_RUN(BF16)
   } else if (dtype == ED_F16) {
@@ -622,18 +813,21 @@ int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void
 }
 
 int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, const void* res_bias, void* out, int dtype,
-                         int N, int C, int HW, void* stream) {
+                         int N, int C, int HW, int channels_last, void* stream) {
   if (N == 0) return 0;
-  if (HW % 8 != 0 || (((uintptr_t)h | (uintptr_t)res | (uintptr_t)out) & 15u)) return (int)hipErrorInvalidValue;
+  if ((channels_last ? C % 8 : HW % 8) != 0 || (((uintptr_t)h | (uintptr_t)res | (uintptr_t)out) & 15u))
+    return (int)hipErrorInvalidValue;
   int64_t total_vec = (int64_t)N * C * HW / 8;
   int grid = (int)((total_vec + 255) / 256 < 8192 ? (total_vec + 255) / 256 : 8192);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == ED_BF16)
     k_bias_residual_add<BF16><<<grid, 256, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
-                                                   (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec);
+                                                   (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec,
+                                                   channels_last);
   else if (dtype == ED_F16)
     k_bias_residual_add<F16><<<grid, 256, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
-                                                  (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec);
+                                                  (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec,
+                                                  channels_last);
   else
     return (int)hipErrorInvalidValue;
   return done();

@@ -26,9 +26,10 @@ FUSED_KERNELS = True
 
 
 # Channels-last activations end to end (MIOpen's CK convolutions are NHWC; NCHW costs a transpose around every conv,
-# 2.4 % of GPU time in profiles/r1_bench_sdxl_1024x2048_kernel_stats_final.csv).  Off until the NHWC convolution shapes
-# have been through a MIOpen find pass and the end-to-end A/B is measured.
-CHANNELS_LAST = False
+# 3 % of GPU time in profiles/r2_s2_bench_sdxl_1024x2048_kernel_stats.csv, and the NHWC form of the same CK instance
+# measured 0.80 vs 0.99 ms on the 320->320 3x3 convolution at batch 20).  The in-tree MIOpen db carries NHWC entries
+# derived from the tuned NCHW ones (tools/miopen_nhwc_from_nchw.py).  A/B switch; see DESIGN.md for the measured result.
+CHANNELS_LAST = os.environ.get("ED_CHANNELS_LAST", "0") == "1"
 
 
 def _fusable(x):
@@ -46,21 +47,24 @@ def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=
     kernel.  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
     N, C, H, W = x.shape
     cpg = C // norm.num_groups
+    nhwc = _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8
     if (chan_bias is not None or conv_bias is not None) and not (
-            FUSED_TEMB_ADD and _fusable(x) and (H * W) % 8 == 0 and not tokens):
+            FUSED_TEMB_ADD and (nhwc or (_fusable(x) and (H * W) % 8 == 0 and not tokens))):
         if conv_bias is not None:
             x = x + conv_bias[None, :, None, None]
         if chan_bias is not None:
             x = x + chan_bias[:, :, None, None]
         chan_bias = conv_bias = None
+        nhwc = _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8
+    if nhwc:
+        from . import ops
+        y = ops.groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu,
+                               chan_bias=None if chan_bias is None else chan_bias.contiguous(), conv_bias=conv_bias)
+        return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y  # a view: NHWC memory is the token layout
     if chan_bias is not None or conv_bias is not None:
         from . import ops
         return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu,
                              chan_bias=None if chan_bias is None else chan_bias.contiguous(), conv_bias=conv_bias)
-    if _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8:
-        from . import ops
-        y = ops.groupnorm_nhwc(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
-        return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y  # a view: NHWC memory is the token layout
     if _fusable(x) and (H * W) % 8 == 0 and (not tokens or cpg % 4 == 0):
         from . import ops
         return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, tokens=tokens)
@@ -160,7 +164,9 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb=None):
         tb = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
         sc = self.conv_shortcut
-        if FUSED_CONV_BIAS and FUSED_TEMB_ADD and _fusable(x) and (x.shape[2] * x.shape[3]) % 8 == 0:
+        cout = self.conv1.out_channels
+        cl = _fusable_nhwc(x) and cout % 8 == 0 and cout // self.norm2.num_groups >= 8
+        if FUSED_CONV_BIAS and FUSED_TEMB_ADD and (cl or (_fusable(x) and (x.shape[2] * x.shape[3]) % 8 == 0)):
             # MIOpen adds a convolution's bias with a separate broadcast kernel: run the convolutions bias-free and fold
             # conv1's bias (+ temb) into norm2's passes, conv2's and the shortcut's into the closing residual add
             from . import ops
@@ -169,7 +175,12 @@ class ResnetBlock2D(nn.Module):
             h = F.conv2d(a, self.conv2.weight, None, padding=1)
             if sc is None:
                 return ops.bias_residual_add(h, self.conv2.bias, x)
-            return ops.bias_residual_add(h, self.conv2.bias, F.conv2d(x, sc.weight, None), sc.bias)
+            if cl:  # channels-last: the 1x1 shortcut is a plain GEMM over the token view, no layout change
+                w = sc.weight.reshape(cout, -1)
+                res = F.linear(x.permute(0, 2, 3, 1), w).permute(0, 3, 1, 2)
+            else:
+                res = F.conv2d(x, sc.weight, None)
+            return ops.bias_residual_add(h, self.conv2.bias, res, sc.bias)
         h = self.conv1(group_norm_act(self.norm1, x, silu=True))
         a = group_norm_act(self.norm2, h, silu=True, chan_bias=tb)  # GroupNorm(h + temb) (+SiLU)
         if sc is not None and SHORTCUT_AS_GEMM and _fusable(x):

@@ -16,6 +16,13 @@ _DTYPE = {torch.float32: ED_F32, torch.float16: ED_F16, torch.bfloat16: ED_BF16}
 _LAUNCH = {"device": None}
 
 
+def _stream_of(t):
+    """``_stream`` for wrappers whose tensor arguments are not all checked through ``_dev`` (non-default strides)."""
+    if _LAUNCH["device"] is None:
+        _LAUNCH["device"] = t.device
+    return _stream()
+
+
 def _stream():
     dev = _LAUNCH["device"]
     if dev is None:
@@ -322,6 +329,9 @@ def geglu(x2, inner):
     return out
 
 
+GROUPNORM_SPLIT = True  # large groups: statistics + apply as two fully parallel launches (A/B switch)
+
+
 def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False, chan_bias=None, conv_bias=None):
     """x [N,C,H,W] NCHW 16-bit -> GroupNorm(+SiLU) as [N,C,H,W], or [N,H*W,C] when ``tokens``.
     ``conv_bias`` [C] / ``chan_bias`` [N,C] (optional): normalise round16(round16(x + conv_bias) + chan_bias) instead of
@@ -333,25 +343,32 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, tokens=False, chan_bias=N
         assert tuple(conv_bias.shape) == (C,)
     out = torch.empty((N, H * W, C) if tokens else (N, C, H, W), dtype=x.dtype, device=x.device)
     TIMER.note_work("ed_groupnorm", nbytes=3.0 * x.numel() * x.element_size())  # statistics pass + apply pass + write
+    ws = None
+    if GROUPNORM_SPLIT:
+        nbytes = _hip.lib().ed_groupnorm_workspace(N, C, H * W, groups)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
     _call("ed_groupnorm", _dev(x, None, "x"), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
           _opt(conv_bias, x.dtype, "conv_bias"), _opt(chan_bias, x.dtype, "chan_bias"), _dev(out, None, "out"),
-          _code(x, "x"), N, C, H * W, groups, float(eps),
+          _opt(ws, torch.float32, "workspace"), _code(x, "x"), N, C, H * W, groups, float(eps),
           int(silu), int(tokens), _stream())
     return out
 
 
-def groupnorm_nhwc(x, gamma, beta, groups, eps, silu=False):
-    """x [N,C,H,W] in torch.channels_last memory format (16-bit) -> GroupNorm(+SiLU), same format."""
+def groupnorm_nhwc(x, gamma, beta, groups, eps, silu=False, chan_bias=None, conv_bias=None):
+    """x [N,C,H,W] in torch.channels_last memory format (16-bit) -> GroupNorm(+SiLU), same format; optional
+    ``conv_bias`` [C] / ``chan_bias`` [N,C] as in ``groupnorm``."""
     N, C, H, W = x.shape
+    if not x.is_cuda:
+        _reject("x must be a tensor on the MI355X; no CPU fallback")
     if not x.is_contiguous(memory_format=torch.channels_last):
-        raise RuntimeError("x must be channels_last")
+        _reject("x must be channels_last")
     out = torch.empty_like(x, memory_format=torch.channels_last)
     nbytes = _hip.lib().ed_groupnorm_nhwc_workspace(N, C, H * W, groups)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    if not x.is_cuda:
-        raise RuntimeError("x must be a tensor on the MI355X; no CPU fallback")
-    _call("ed_groupnorm_nhwc", x.data_ptr(), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"), out.data_ptr(),
-          ws.data_ptr(), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), _stream())
+    TIMER.note_work("ed_groupnorm_nhwc", nbytes=3.0 * x.numel() * x.element_size())
+    _call("ed_groupnorm_nhwc", x.data_ptr(), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
+          _opt(conv_bias, x.dtype, "conv_bias"), _opt(chan_bias, x.dtype, "chan_bias"), out.data_ptr(),
+          _dev(ws, torch.float32, "workspace"), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), _stream())
     return out
 
 
@@ -378,13 +395,18 @@ def add_layernorm(a, b, gamma, beta, eps):
 
 
 def bias_residual_add(h, h_bias, res, res_bias=None):
-    """round16(res (+ res_bias[c])) + round16(h + h_bias[c]) for NCHW 16-bit tensors (ResnetBlock2D's closing add)."""
+    """round16(res (+ res_bias[c])) + round16(h + h_bias[c]) for 16-bit [N,C,H,W] tensors that are both NCHW-contiguous
+    or both channels_last (ResnetBlock2D's closing add); the result has the same memory format."""
     N, C, H, W = h.shape
     assert res.shape == h.shape and res.dtype == h.dtype
-    out = torch.empty_like(h)
+    cl = (not h.is_contiguous()) and h.is_contiguous(memory_format=torch.channels_last)
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    if not (h.is_cuda and res.is_cuda and h.is_contiguous(memory_format=fmt) and res.is_contiguous(memory_format=fmt)):
+        _reject("bias_residual_add: h and res must be MI355X tensors in the same (NCHW or channels_last) dense format")
+    out = torch.empty_like(h, memory_format=fmt)
     TIMER.note_work("ed_bias_residual_add", nbytes=3.0 * h.numel() * h.element_size())
-    _call("ed_bias_residual_add", _dev(h, None, "h"), _opt(h_bias, h.dtype, "h_bias"), _dev(res, None, "res"),
-          _opt(res_bias, h.dtype, "res_bias"), _dev(out, None, "out"), _code(h, "h"), N, C, H * W, _stream())
+    _call("ed_bias_residual_add", h.data_ptr(), _opt(h_bias, h.dtype, "h_bias"), res.data_ptr(),
+          _opt(res_bias, h.dtype, "res_bias"), out.data_ptr(), _code(h, "h"), N, C, H * W, int(cl), _stream_of(h))
     return out
 
 

@@ -189,19 +189,26 @@ int ed_geglu(const void* in, void* out, int dtype, int64_t M, int I, void* strea
  *   round16(round16(x + conv_bias[c]) + chan_bias[n,c]) -- the bias of the convolution that produced x (run bias-free:
  *   MIOpen would add it in a separate broadcast kernel) and the time-embedding add `h + temb[:, :, None, None]` that
  *   precedes norm2 in ResnetBlock2D, folded into both passes with the roundings of the kernels they replace;
+ *   workspace: caller-owned fp32 scratch of ed_groupnorm_workspace(N, C, HW, G) bytes, or NULL.  Groups larger than
+ *   64 K elements are then normalised by two fully parallel launches (per-chunk Welford partials, merged in order --
+ *   deterministic) instead of one workgroup per (sample, group); with NULL (or small groups: workspace size 0) the
+ *   single-launch kernel runs.
  *   HW % 8 == 0, C % G == 0 (and (C/G) % 4 == 0 for tokens_out); dtype = ED_F16 | ED_BF16.
  */
 int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
-                 void* out, int dtype, int N, int C, int HW, int G, float eps, int act_silu, int tokens_out, void* stream);
+                 void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
+                 int tokens_out, void* stream);
+int64_t ed_groupnorm_workspace(int N, int C, int HW, int G);
 
 /*
  * ed_bias_residual_add -- ResnetBlock2D's closing add with the convolution biases folded in:
  *   out[n,c,p] = round16(res[n,c,p] (+ res_bias[c])) + round16(h[n,c,p] + h_bias[c])
  * h = conv2 output (bias-free), res = the block input or the bias-free 1x1 shortcut convolution; either bias may be NULL.
- * [N,C,HW] 16-bit NCHW contiguous, HW % 8 == 0; dtype = ED_F16 | ED_BF16.
+ * 16-bit; channels_last == 0: [N,C,HW] NCHW contiguous, HW % 8 == 0; channels_last != 0: [N,HW,C] memory (torch
+ * channels_last), C % 8 == 0; dtype = ED_F16 | ED_BF16.
  */
 int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, const void* res_bias, void* out, int dtype,
-                         int N, int C, int HW, void* stream);
+                         int N, int C, int HW, int channels_last, void* stream);
 
 /*
  * ed_layernorm -- LayerNorm over the last dimension of [M, D] 16-bit activations (BasicTransformerBlock.norm1/2/3):
@@ -230,10 +237,12 @@ int ed_tokens_add_nchw(const void* x, const void* tokens, void* out, int dtype, 
  * ed_groupnorm_nhwc -- the same GroupNorm [+ SiLU] for channels-last activations: x / out dtype [N, HW, C] (the memory
  * of an NCHW tensor in torch.channels_last format, which is also the transformer's token layout).  Three launches
  * (partial sums, finalise in double, vectorised apply); `workspace` is caller-owned fp32 scratch of
- * ed_groupnorm_nhwc_workspace(N, C, HW, G) bytes.  C % 8 == 0, C % G == 0, C / G >= 8, G <= 256; dtype = ED_F16 | ED_BF16.
+ * ed_groupnorm_nhwc_workspace(N, C, HW, G) bytes.  conv_bias [C] / chan_bias [N,C] (optional) as in ed_groupnorm.
+ * C % 8 == 0, C % G == 0, C / G >= 8, G <= 256; dtype = ED_F16 | ED_BF16.
  */
-int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N,
-                      int C, int HW, int G, float eps, int act_silu, void* stream);
+int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+                      void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
+                      void* stream);
 int64_t ed_groupnorm_nhwc_workspace(int N, int C, int HW, int G);
 
 /*

@@ -63,5 +63,7 @@ def test_fused_kernels_are_inside_the_bf16_loop():
         R.run_product(c, unet, vae, cn, torch.bfloat16)
     finally:
         ops._call = orig
-    need = {"ed_pick_assemble", "ed_gather_views"} | M.fused_unet_entry_points()
+    from elasticdiffusion_official_amd import pipeline
+    glue = {"ed_assemble_rows", "ed_phase_epilogue"} if pipeline.FUSED_GLUE else {"ed_pick_assemble", "ed_gather_views"}
+    need = glue | M.fused_unet_entry_points()
     assert need <= seen, sorted(need - seen)

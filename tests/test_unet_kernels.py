@@ -118,6 +118,11 @@ def test_groupnorm_channels_last(dtype, N, C, H, W, silu):
     # token view of the result == permute of the NCHW result
     tok = got.permute(0, 2, 3, 1).reshape(N, H * W, C)
     assert tok.data_ptr() == got.data_ptr()
+    # folded convolution bias + time-embedding add: exactly the kernel applied to the pre-added tensor
+    kb, cb = torch.randn(C, device=DEV).to(dtype), torch.randn(N, C, device=DEV).to(dtype)
+    pre = ((x + kb[None, :, None, None]) + cb[:, :, None, None]).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=silu, chan_bias=cb, conv_bias=kb),
+                       ops.groupnorm_nhwc(pre, w, b, 32, 1e-5, silu=silu))
 
 
 def test_unet_channels_last_path_close():
@@ -252,6 +257,37 @@ def test_tokens_add_nchw(dtype, N, C, H, W):
     assert got.is_contiguous() and torch.equal(got, want.contiguous())
 
 
+@pytest.mark.parametrize("N,C,H,W,tokens", [(2, 320, 128, 128, False), (2, 640, 64, 64, True), (1, 960, 128, 128, False),
+                                            (3, 1920, 64, 64, False)])
+def test_groupnorm_split_path_for_large_groups(N, C, H, W, tokens):
+    """Groups above 64 K elements take the two-launch (chunked Welford partials + apply) path: same accuracy bar as the
+    single-launch kernel, and the two agree to within one 16-bit ulp (the statistics are merged in a different order)."""
+    from elasticdiffusion_official_amd import ops
+    dtype = torch.bfloat16
+    x = (torch.randn(N, C, H, W, device=DEV) * 1.7 + 0.3).to(dtype)
+    w = (1 + 0.2 * torch.randn(C, device=DEV)).to(dtype)
+    b = (0.1 * torch.randn(C, device=DEV)).to(dtype)
+    cb = torch.randn(N, C, device=DEV).to(dtype)
+    kb = torch.randn(C, device=DEV).to(dtype)
+    kw = dict(silu=True, tokens=tokens) if tokens else dict(silu=True, chan_bias=cb, conv_bias=kb)
+    assert ops._hip.lib().ed_groupnorm_workspace(N, C, H * W, 32) > 0
+    got = ops.groupnorm(x, w, b, 32, 1e-5, **kw)
+    ops.GROUPNORM_SPLIT = False
+    try:
+        one = ops.groupnorm(x, w, b, 32, 1e-5, **kw)
+    finally:
+        ops.GROUPNORM_SPLIT = True
+    xin = x.float() if tokens else (x + kb[None, :, None, None] + cb[:, :, None, None]).float()
+    ref = F.silu(F.group_norm(xin, 32, w.float(), b.float(), 1e-5))
+    if tokens:
+        ref = ref.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    ulp = 2.0 ** -8
+    for y in (got, one):
+        assert bool(((y.float() - ref).abs() <= 2.0 * ulp * ref.abs() + 4 * ulp).all())
+    assert float((got.float() - one.float()).abs().max()) <= float((2 * ulp * ref.abs() + 2 * ulp).max())
+    print(f"groupnorm split vs single launch {N}x{C}x{H}x{W}: identical {float((got == one).float().mean()):.4f}")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 640, 16, 16), (2, 64, 4, 2)])
 def test_groupnorm_with_channel_bias(dtype, N, C, H, W):
@@ -282,6 +318,10 @@ def test_bias_residual_add(dtype, N, C, H, W):
     assert torch.equal(ops.bias_residual_add(h, hb, res), res + (h + bc(hb)))
     assert torch.equal(ops.bias_residual_add(h, hb, res, rb), (res + bc(rb)) + (h + bc(hb)))
     assert torch.equal(ops.bias_residual_add(h, None, res), res + h)
+    if C % 8 == 0:  # channels-last operands: same values, channels-last result
+        hc, rc = (t.contiguous(memory_format=torch.channels_last) for t in (h, res))
+        got = ops.bias_residual_add(hc, hb, rc, rb)
+        assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, (res + bc(rb)) + (h + bc(hb)))
 
 
 def test_unet_round2_fusions_close():

@@ -76,12 +76,25 @@ def probe_fused():
     t_f = ev_time(lambda: ops.groupnorm(x, w, bb, 32, 1e-5, silu=True, chan_bias=cb))
     t_u = ev_time(lambda: ops.groupnorm(x + cb[:, :, None, None], w, bb, 32, 1e-5, silu=True))
     emit(probe="groupnorm_chan_bias", shape=list(x.shape), fused_us=round(t_f, 1), add_then_gn_us=round(t_u, 1))
+    for shape in [(20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1280, 32, 32), (6, 320, 128, 128)]:
+        x = torch.randn(*shape, device=DEV).to(torch.bfloat16)
+        w, bb = torch.ones(shape[1], device=DEV, dtype=torch.bfloat16), torch.zeros(shape[1], device=DEV, dtype=torch.bfloat16)
+        res = {}
+        for split in (True, False):
+            ops.GROUPNORM_SPLIT = split
+            t = ev_time(lambda: ops.groupnorm(x, w, bb, 32, 1e-5, silu=True))
+            res["split_us" if split else "single_us"] = round(t, 1)
+            res["split_gbs" if split else "single_gbs"] = round(3 * x.numel() * 2 / t / 1e3, 1)
+        ops.GROUPNORM_SPLIT = True
+        emit(probe="groupnorm_split", shape=list(shape), **res)
 
 
 def build_unet():
     torch.manual_seed(0)
     cfg = M.UNET_CONFIGS["sdxl"]
     unet = M.UNet2DConditionModel(**cfg).to(DEV, torch.bfloat16).eval().requires_grad_(False)
+    if M.CHANNELS_LAST:
+        unet = unet.to(memory_format=torch.channels_last)
     return unet, cfg
 
 
@@ -103,7 +116,7 @@ def probe_unet(unet, cfg):
             with torch.no_grad():
                 return unet(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)
 
-        res = {"B": B}
+        res = {"B": B, "channels_last": M.CHANNELS_LAST}
         res["all_on_ms"] = round(ev_time(fwd, reps=3, warm=2) / 1e3, 2)
         for n in names:
             setattr(M, n, False)
