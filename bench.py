@@ -78,6 +78,11 @@ def algorithmic_bytes(name, wl_geo):
         "ed_gather_views": L + V * B * row,
         # mean over the two call shapes (K = R+1 and K = 1) is reported by the caller using launches-weighted K
         "ed_pick_assemble": lambda k: k * (l + h * w) + 2 * k * B * row + k * l,
+        # fused: pick + gather in one launch
+        "ed_assemble_rows": lambda k: k * (l + h * w) + 2 * k * B * row + k * l + L + V * B * row,
+        # fused epilogue: per full-res element one (cond, uncond) pair of the covering step (16 bit) + one view-centre
+        # value (16 bit) + x in, prev / x0 / x_next out (fp32) + the stamp table; reduced by-products: 3 l in, 2 l out
+        "ed_phase_epilogue": lambda k: (L // 4) * (2 * mb + mb) + 4 * L + 4 * h * w + 5 * l,
         "ed_unpad_direction": lambda k: 2 * k * B * row // 2 + k * l + l,
         "ed_fill_directions": lambda k: k * l + 4 * h * w + L + l,
     }[name]
@@ -117,7 +122,14 @@ def glue_launchers(dev, wl, T, mdt):
     up_row, up_col, down_row, down_col = i32(pick.up_row), i32(pick.up_col), i32(pick.down_row), i32(pick.down_col)
     win_y0, win_x0 = i32(views.win_y0), i32(views.win_x0)
     rb, rs, cb, cs = (i32(a) for a in views.cover_tables(vpad.top, vpad.left))
+    pick_t = (inv_row, inv_col, up_row, up_col, down_row, down_col)
     return {
+        "ed_assemble_rows": lambda: ops.assemble_rows(x, idx, src_row, src_col, rows[:n_g], h, w, gpad.top, gpad.left, frame, low,
+                                                      rows[n_g:], win_y0, win_x0, views.Sh, views.Sw, vpad.top, vpad.left, None),
+        "ed_phase_epilogue": lambda: ops.phase_epilogue(out[:n_g], out[n_g:], x, stamp, pick_t, (rb, rs, cb, cs), views.n_col_blocks,
+                                                        (gpad.top, gpad.left), K, h, w, 3.3, (0.9, 0.4, 0.5, 0.8), prev, x0,
+                                                        low_dir=low_dir, uncond_last=unc, x_next=nxt, low_latent=low[K - 1],
+                                                        rrg_norm=np.float32(2.0 / x.numel()), rrg_weight=800.0),
         "ed_pick_assemble": lambda: ops.pick_assemble(x, idx, src_row, src_col, rows[:n_g], h, w, gpad.top, gpad.left, frame, low),
         "ed_gather_views": lambda: ops.gather_views(x, rows[n_g:], win_y0, win_x0, views.Sh, views.Sw, vpad.top, vpad.left, None),
         "ed_unpad_direction": lambda: ops.unpad_direction(out[:n_g], dirs, unc, gpad.top, gpad.left),

@@ -319,68 +319,74 @@ k_gn_split_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ ga
 // output *is* the transformer's token layout (no permute copy) and the layout MIOpen's CK convolutions consume.
 #define GNL_THREADS 256
 
+// Every thread owns a fixed 8-channel column (two when C > 2048) and walks rows, so its sums stay in registers; the
+// reduction over row lanes and then over the columns of each group goes through LDS in a fixed order: no atomics,
+// bit-reproducible statistics.  (The first version re-binned per item with LDS float atomics whenever C/8 did not divide
+// the block size -- every SDXL width -- which was both slow and run-to-run non-deterministic.)
+#define GNL_MAXCOL 2  // columns per thread: C <= 8 * 256 * GNL_MAXCOL = 4096
 template <typename T>
 __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ conv_bias,
                   const uint16_t* __restrict__ chan_bias, float* __restrict__ partial, int C, int HW, int G,
                   int rows_per_block) {
-  // block (n, chunk): rows [chunk*rows_per_block, ...) of sample n; thread t walks (row, vec8) pairs with stride 256
-  extern __shared__ float sh[];  // [G*2] group sums
+  extern __shared__ float sh[];  // [lanes][VC][4]: (sum, sumsq) of the column's first / second group part
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int VC = C >> 3, cpg = C / G;
-  for (int i = threadIdx.x; i < 2 * G; i += GNL_THREADS) sh[i] = 0.f;
-  __syncthreads();
-  int r0 = chunk * rows_per_block;
-  int r1 = min(HW, r0 + rows_per_block);
+  const int ncol = (VC + GNL_THREADS - 1) / GNL_THREADS;      // 1 or 2 columns per thread
+  const int R = ncol == 1 ? GNL_THREADS / VC : 1;            // row lanes
+  const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
+  const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
+  const bool active = ncol == 1 ? (int)threadIdx.x < R * VC : true;
+  const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
   const uint16_t* base = x + (int64_t)n * HW * C;
   const uint16_t* cbn = chan_bias ? chan_bias + (int64_t)n * C : nullptr;
   const bool has_cb = cbn != nullptr, has_kb = conv_bias != nullptr;
-  int64_t total = (int64_t)(r1 - r0) * VC;
-  // a thread's successive items advance by 256 vectors; when VC divides 256 (or vice versa) it keeps the same
-  // channels, in general it does not, so sums are binned per item into at most two groups
-  float acc_s[2] = {0.f, 0.f}, acc_q[2] = {0.f, 0.f};
-  int acc_g = -1;
-  for (int64_t it = threadIdx.x; it < total; it += GNL_THREADS) {
-    int row = r0 + (int)(it / VC);
-    int vc = (int)(it % VC);
-    int c0 = vc << 3;
-    U16x8 v = *reinterpret_cast<const U16x8*>(base + (int64_t)row * C + c0);
-    int g0 = c0 / cpg;
-    if (g0 != acc_g) {  // flush the accumulators when the thread moves to other channels
-      if (acc_g >= 0) {
-        atomicAdd(&sh[2 * acc_g], acc_s[0]);
-        atomicAdd(&sh[2 * acc_g + 1], acc_q[0]);
-        if (acc_g + 1 < G && (acc_s[1] != 0.f || acc_q[1] != 0.f)) {
-          atomicAdd(&sh[2 * (acc_g + 1)], acc_s[1]);
-          atomicAdd(&sh[2 * (acc_g + 1) + 1], acc_q[1]);
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < GNL_MAXCOL; ++j) {
+      const int vc = my_c + j * GNL_THREADS;
+      if (j >= ncol || vc >= VC) break;
+      const int c0 = vc << 3;
+      const int split = (c0 / cpg + 1) * cpg - c0;  // channels [0, split) of the vector belong to its first group
+      U16x8 kbv, cbv;
+      if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
+      if (has_cb) cbv = *reinterpret_cast<const U16x8*>(cbn + c0);
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+      for (int row = r0 + my_r; row < r1; row += R) {
+        U16x8 v = *reinterpret_cast<const U16x8*>(base + (int64_t)row * C + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
+          if (e < split) {
+            s0 += f;
+            q0 += f * f;
+          } else {
+            s1 += f;
+            q1 += f * f;
+          }
         }
       }
-      acc_g = g0;
-      acc_s[0] = acc_s[1] = acc_q[0] = acc_q[1] = 0.f;
-    }
-    int split = (g0 + 1) * cpg - c0;  // channels [0, split) of this vector belong to g0, the rest to g0+1
-    U16x8 kbv, cbv;
-    if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
-    if (has_cb) cbv = *reinterpret_cast<const U16x8*>(cbn + c0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
-      int k = e < split ? 0 : 1;
-      acc_s[k] += f;
-      acc_q[k] += f * f;
-    }
-  }
-  if (acc_g >= 0) {
-    atomicAdd(&sh[2 * acc_g], acc_s[0]);
-    atomicAdd(&sh[2 * acc_g + 1], acc_q[0]);
-    if (acc_g + 1 < G && (acc_s[1] != 0.f || acc_q[1] != 0.f)) {
-      atomicAdd(&sh[2 * (acc_g + 1)], acc_s[1]);
-      atomicAdd(&sh[2 * (acc_g + 1) + 1], acc_q[1]);
+      float* slot = sh + ((int64_t)my_r * VC + vc) * 4;
+      slot[0] = s0, slot[1] = q0, slot[2] = s1, slot[3] = q1;
     }
   }
   __syncthreads();
+  // group g: its columns in ascending order, row lanes in ascending order inside each
   float* dst = partial + ((int64_t)n * gridDim.x + chunk) * 2 * G;
-  for (int i = threadIdx.x; i < 2 * G; i += GNL_THREADS) dst[i] = sh[i];
+  for (int g = threadIdx.x; g < G; g += GNL_THREADS) {
+    const int cfirst = (g * cpg) >> 3, clast = ((g + 1) * cpg - 1) >> 3;
+    float s = 0.f, q = 0.f;
+    for (int vc = cfirst; vc <= clast; ++vc) {
+      const int part = ((vc << 3) / cpg == g) ? 0 : 1;  // this column's first group is g, or g is its second one
+      for (int r = 0; r < R; ++r) {
+        const float* slot = sh + ((int64_t)r * VC + vc) * 4 + 2 * part;
+        s += slot[0];
+        q += slot[1];
+      }
+    }
+    dst[2 * g] = s;
+    dst[2 * g + 1] = q;
+  }
 }
 
 __global__ void k_gn_nhwc_finalize(const float* __restrict__ partial, float* __restrict__ stats, int G, int nchunks,
@@ -420,10 +426,12 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
     if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
     if (has_cb) cbv = *reinterpret_cast<const U16x8*>(chan_bias + (int64_t)n * C + c0);
     U16x8 o;
+    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;  // C/G >= 8: a vector touches at most two groups
+    const float mean0 = stats[2 * (n * G + g0)], rstd0 = stats[2 * (n * G + g0) + 1];
+    const float mean1 = split < 8 ? stats[2 * (n * G + g0 + 1)] : 0.f, rstd1 = split < 8 ? stats[2 * (n * G + g0 + 1) + 1] : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int g = (c0 + e) / cpg;
-      float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+      const float mean = e < split ? mean0 : mean1, rstd = e < split ? rstd0 : rstd1;
       float a = rstd * T::to_f32(gm.v[e]);
       float b = fmaf(-a, mean, T::to_f32(bt.v[e]));
       float xin = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
@@ -732,7 +740,7 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
                       void* stream) {
   if (N == 0) return 0;
   // C/G >= 8: an 8-channel vector then touches at most two groups (what the partial-sum kernel bins into)
-  if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 ||
+  if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 || C > 8 * GNL_THREADS * GNL_MAXCOL ||
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -743,7 +751,8 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
   float* partial = workspace;                                // [N, nchunks, G, 2]
   float* stats = workspace + (int64_t)N * nchunks * G * 2;   // [N, G, 2]
   dim3 grid1(nchunks, N);
-  size_t lds = sizeof(float) * 2 * G;
+  const int VC_ = C / 8;
+  size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= GNL_THREADS ? GNL_THREADS / VC_ : 1);
   int64_t total_vec = (int64_t)N * HW * (C / 8);
   int grid3 = (int)((total_vec + GNL_THREADS - 1) / GNL_THREADS < 8192 ? (total_vec + GNL_THREADS - 1) / GNL_THREADS : 8192);
   int NG = N * G;

@@ -25,11 +25,14 @@ import torch.nn.functional as F
 FUSED_KERNELS = True
 
 
-# Channels-last activations end to end (MIOpen's CK convolutions are NHWC; NCHW costs a transpose around every conv,
-# 3 % of GPU time in profiles/r2_s2_bench_sdxl_1024x2048_kernel_stats.csv, and the NHWC form of the same CK instance
-# measured 0.80 vs 0.99 ms on the 320->320 3x3 convolution at batch 20).  The in-tree MIOpen db carries NHWC entries
-# derived from the tuned NCHW ones (tools/miopen_nhwc_from_nchw.py).  A/B switch; see DESIGN.md for the measured result.
-CHANNELS_LAST = os.environ.get("ED_CHANNELS_LAST", "0") == "1"
+# Channels-last activations end to end: MIOpen's CK convolutions are NHWC kernels, and an NCHW problem costs a layout
+# transpose on either side of every convolution (batched_transpose_*: 5.9 ms of a 178 ms batch-20 forward,
+# profiles/r2_s5_unet_fwd_b20_nchw_kernel_stats.csv).  With channels-last activations those launches disappear, GroupNorm's
+# token-layout output and the transformer's closing residual add become plain views / contiguous adds, and the 1x1
+# shortcut convolutions are plain GEMMs.  Measured (hipGraph replay, profiles/r2_s5_probe_channels_last.jsonl):
+# 168.6 vs 174.9 ms at batch 20, 60.0 vs 61.4 ms at batch 6.  The in-tree MIOpen db carries NHWC entries derived from the
+# tuned NCHW ones (tools/miopen_nhwc_from_nchw.py).  ED_CHANNELS_LAST=0 switches back (A/B).
+CHANNELS_LAST = os.environ.get("ED_CHANNELS_LAST", "1") == "1"
 
 
 def _fusable(x):
@@ -91,10 +94,11 @@ for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
 def fused_unet_entry_points():
     """C-ABI entry points a 16-bit UNet forward reaches with the current switches (the real-architecture parity test
     checks that they were actually launched, i.e. that no torch fallback silently took over)."""
-    on = [("ed_groupnorm", FUSED_KERNELS), ("ed_geglu", FUSED_KERNELS), ("ed_layernorm", FUSED_KERNELS and FUSED_LAYERNORM),
+    on = [("ed_groupnorm_nhwc" if CHANNELS_LAST else "ed_groupnorm", FUSED_KERNELS), ("ed_geglu", FUSED_KERNELS),
+          ("ed_layernorm", FUSED_KERNELS and FUSED_LAYERNORM),
           ("ed_flash_attention", FUSED_KERNELS and FLASH_ATTENTION),
           ("ed_add_layernorm", FUSED_KERNELS and FUSED_ADD_LAYERNORM),
-          ("ed_tokens_add_nchw", FUSED_KERNELS and FUSED_TOKENS_ADD),
+          ("ed_tokens_add_nchw", FUSED_KERNELS and FUSED_TOKENS_ADD and not CHANNELS_LAST),
           ("ed_bias_residual_add", FUSED_KERNELS and FUSED_CONV_BIAS and FUSED_TEMB_ADD)]
     return {n for n, flag in on if flag}
 
@@ -476,7 +480,7 @@ class UNet2DConditionModel(nn.Module):
     def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
         x = sample.to(self.dtype)
-        if CHANNELS_LAST:
+        if CHANNELS_LAST and x.is_cuda and x.dtype != torch.float32:
             x = x.contiguous(memory_format=torch.channels_last)
         ctx = encoder_hidden_states.to(self.dtype)
         emb = self.embed(x, timestep, added_cond_kwargs)
@@ -554,9 +558,13 @@ class ControlNetModel(nn.Module):
     def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0,
                 guess_mode=False, return_dict=False, added_cond_kwargs=None, **_):
         x = sample.to(self.dtype)
+        cond = controlnet_cond.to(self.dtype)
+        if CHANNELS_LAST and x.is_cuda and x.dtype != torch.float32:
+            x = x.contiguous(memory_format=torch.channels_last)
+            cond = cond.contiguous(memory_format=torch.channels_last)
         ctx = encoder_hidden_states.to(self.dtype)
         emb = self.embed(x, timestep, added_cond_kwargs)
-        x = self.conv_in(x) + self.controlnet_cond_embedding(controlnet_cond.to(self.dtype))
+        x = self.conv_in(x) + self.controlnet_cond_embedding(cond)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk(x, emb, ctx)
@@ -753,8 +761,8 @@ def build_models(sd_version, device="cuda", dtype=None, weights=None, vae_dtype=
             load_weights(m, f)
         else:
             _seeded_init(m, seed + k)
-        m = m.to(dtype=dt).eval().requires_grad_(False)  # NCHW: measured 5 % faster than channels_last end to end
-        if CHANNELS_LAST and sub != "vae":
+        m = m.to(dtype=dt).eval().requires_grad_(False)
+        if CHANNELS_LAST and sub != "vae" and dt != torch.float32:  # 16-bit UNet / ControlNet; the fp32 VAE stays NCHW
             m = m.to(memory_format=torch.channels_last)
         out.append(m)
     return tuple(out)

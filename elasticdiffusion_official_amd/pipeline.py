@@ -178,9 +178,9 @@ class ElasticDiffusion(nn.Module):
             built_unet, built_vae = build_models(sd_version, device=device, dtype=model_dtype, weights=weights)
             unet = unet if unet is not None else built_unet
             vae = vae if vae is not None else built_vae
-        self.unet = unet.to(device)
+        self.unet = self._model_layout(unet.to(device))
         self.vae = vae.to(device)
-        self.controlnet = controlnet.to(device) if controlnet is not None else None
+        self.controlnet = self._model_layout(controlnet.to(device)) if controlnet is not None else None
         if scheduler is None:
             scheduler = DDIMSchedule.from_config_dir(weights) if weights else DDIMSchedule()  # ED:153
         self.scheduler = scheduler
@@ -205,6 +205,16 @@ class ElasticDiffusion(nn.Module):
         self.default_size = None
         self._stager = _Stager()
         self.last_latents = None
+
+    @staticmethod
+    def _model_layout(module):
+        """16-bit UNet / ControlNet weights in the memory format the forward runs in (models.CHANNELS_LAST), so that no
+        convolution has to re-lay-out its filter on every call; idempotent, and a no-op for fp32 / injected stand-ins."""
+        from . import models
+        p = next(module.parameters(), None)
+        if models.CHANNELS_LAST and p is not None and p.dtype in (torch.bfloat16, torch.float16):
+            module = module.to(memory_format=torch.channels_last)
+        return module
 
     def _mark(self, name):
         """Phase markers (HIP events on the current stream; read only by ``phase_times`` after a sync)."""

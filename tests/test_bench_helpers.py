@@ -20,6 +20,9 @@ def test_algorithmic_bytes_table():
     assert bench.algorithmic_bytes("ed_cfg_ddim_step", geo) == 5 * L
     assert bench.algorithmic_bytes("ed_rrg_update", geo) == 3 * L + 3 * l
     assert bench.algorithmic_bytes("ed_pick_assemble", geo)(8) == 8 * (l + 64 * 128) + 16 * 4 * 128 * 128 * 2 + 8 * l
+    assert bench.algorithmic_bytes("ed_assemble_rows", geo)(8) == (bench.algorithmic_bytes("ed_pick_assemble", geo)(8)
+                                                                  + bench.algorithmic_bytes("ed_gather_views", geo))
+    assert bench.algorithmic_bytes("ed_phase_epilogue", geo)(8) == (L // 4) * 6 + 4 * L + 4 * 64 * 128 + 5 * l
     assert set(bench.WORKLOADS) >= {"sdxl_1024x2048", "sd15_512x1024", "sdxl_2048x2048_tiled"}
     wl = bench.WORKLOADS["sdxl_1024x2048"]
     assert (wl["H"], wl["W"], wl["vbs"], wl["R"]) == (1024, 2048, 16, 7)

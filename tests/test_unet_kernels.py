@@ -137,16 +137,22 @@ def test_unet_channels_last_path_close():
     e = torch.randn(3, 77, 64, device=DEV, dtype=torch.bfloat16)
     kw = {"text_embeds": torch.randn(3, 16, device=DEV, dtype=torch.bfloat16), "time_ids": torch.zeros(3, 6, device=DEV)}
     t = torch.tensor(500, device=DEV)
+    saved = M.CHANNELS_LAST
     with torch.no_grad():
-        a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
         try:
+            M.CHANNELS_LAST = False
+            a = u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
             M.CHANNELS_LAST = True
             ucl = u.to(memory_format=torch.channels_last)
             b = ucl(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)["sample"].float()
+            ref = u.float().to(memory_format=torch.contiguous_format)(
+                x.float(), t, encoder_hidden_states=e.float(), added_cond_kwargs={k: v.float() for k, v in kw.items()})["sample"]
         finally:
-            M.CHANNELS_LAST = False
+            M.CHANNELS_LAST = saved
     rel = float((a - b).norm() / a.norm())
-    assert rel < 2e-2, rel
+    ra, rb = float((a - ref).norm() / ref.norm()), float((b - ref).norm() / ref.norm())
+    print(f"UNet bf16 vs fp32: NCHW {ra:.3e}, channels_last {rb:.3e}; NCHW vs channels_last {rel:.3e}")
+    assert rel < 2e-2 and rb < 1.5 * ra + 1e-3, (rel, ra, rb)
     with pytest.raises(RuntimeError):  # channels-per-group < 8 is rejected by the C ABI, never silently wrong
         from elasticdiffusion_official_amd import ops
         xs = torch.randn(1, 32, 4, 4, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)

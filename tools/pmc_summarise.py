@@ -14,13 +14,19 @@ import sys
 from collections import defaultdict
 
 ENTRY = {"k_flash_attn_fwd": "ed_flash_attention", "k_geglu": "ed_geglu", "k_groupnorm": "ed_groupnorm",
-         "k_layernorm": "ed_layernorm", "k_add_layernorm": "ed_add_layernorm", "k_tokens_add_nchw": "ed_tokens_add_nchw",
-         "k_pick_assemble": "ed_pick_assemble", "k_gather_windows": "ed_gather_views", "k_undo_step": "ed_undo_step"}
+         "k_gn_split_stats": "ed_groupnorm[split stats]", "k_gn_split_apply": "ed_groupnorm[split apply]",
+         "k_gn_nhwc_partial": "ed_groupnorm_nhwc[partial]", "k_gn_nhwc_apply": "ed_groupnorm_nhwc[apply]",
+         "k_add_layernorm": "ed_add_layernorm", "k_layernorm": "ed_layernorm", "k_tokens_add_nchw": "ed_tokens_add_nchw",
+         "k_bias_residual_add": "ed_bias_residual_add", "k_assemble_rows": "ed_assemble_rows",
+         "k_phase_epilogue": "ed_phase_epilogue", "k_pick_assemble": "ed_pick_assemble",
+         "k_gather_windows": "ed_gather_views", "k_undo_v4": "ed_undo_step", "k_unpad_direction": "ed_unpad_direction",
+         "k_fill_directions": "ed_fill_directions", "k_scatter_centres": "ed_scatter_centres", "k_cfg_ddim": "ed_cfg_ddim_step",
+         "k_rrg_update": "ed_rrg_update"}
 
 
 def entry_of(kernel):
-    for k, v in ENTRY.items():
-        if re.search(r"\b" + k + r"\b|" + k + "[A-Z<_]", kernel) or k in kernel:
+    for k, v in ENTRY.items():  # dict order: longer, more specific names come before their prefixes
+        if re.search(k + r"(?![a-z])", kernel):
             return v
     return None
 

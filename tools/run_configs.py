@@ -3,8 +3,6 @@ finite outputs, shapes, rough timings.  These are parity-test cases / scope rows
 import os, sys, time
 # smoke runs of shapes that are not bench lines: skip MIOpen's benchmarking search (minutes per new conv shape)
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-os.environ.setdefault("MIOPEN_USER_DB_PATH", "/tmp/miopen_smoke")
-os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", "/tmp/miopen_smoke")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from elasticdiffusion_official_amd import ElasticDiffusion, ElasticDiffusionControlNet
