@@ -101,7 +101,10 @@ __device__ __forceinline__ Vec16 load_row16(const uint16_t* base, int64_t row_st
 // __launch_bounds__(256, 2): at least 2 waves per SIMD => a 256-register budget per lane, which also makes the compiler
 // keep the MFMA accumulators in ordinary VGPRs (gfx950's unified file) instead of shuttling S and O through AGPRs with
 // ~80 v_accvgpr moves per tile.
-template <typename T, bool TR>
+// QN = 32-row query blocks per wave (1: 128 query rows per workgroup, 3 waves/SIMD; 2: 256 rows per workgroup -- every K
+// and V fragment read from LDS feeds two MFMAs, and the per-tile barrier, staging and LDS traffic are amortised over
+// twice the MFMA work, at 2 waves/SIMD).
+template <typename T, bool TR, int QN>
 __global__ void __launch_bounds__(256, 2)
 k_flash_attn_fwd(const Params p) {
   __shared__ Smem<TR> sm;
@@ -128,10 +131,15 @@ k_flash_attn_fwd(const Params p) {
   uint16_t* og = p.o + b * p.o_sb + h * D;
 
   // ---- Q^T fragments (B operand of S^T = K Q^T): lane (q = ln, hi) holds d = 16 ks + 8 hi + [0,8) ------------------
-  const int q_row = qblk * QB + wave * 32 + ln;
-  typename T::v8 qf[4];
+  int q_row[QN];
+  typename T::v8 qf[QN][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = as_v8<typename T::v8>(load_row16(qg, p.q_sn, q_row, p.Nq, 16 * ks + 8 * hi));
+  for (int qn = 0; qn < QN; ++qn) {
+    q_row[qn] = qblk * (QB * QN) + (wave * QN + qn) * 32 + ln;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[qn][ks] = as_v8<typename T::v8>(load_row16(qg, p.q_sn, q_row[qn], p.Nq, 16 * ks + 8 * hi));
+  }
 
   // ---- staging registers for one K/V tile (2 x 16 B each per thread) ---------------------------------------------
   Vec16 kreg[2], vreg[2];
@@ -176,10 +184,14 @@ k_flash_attn_fwd(const Params p) {
     }
   };
 
-  f32x16 oacc[2];
+  f32x16 oacc[QN][2];
+  float m_run[QN], l_run[QN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int qn = 0; qn < QN; ++qn) {
+    m_run[qn] = -INFINITY, l_run[qn] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[qn][0][i] = oacc[qn][1][i] = 0.f;
+  }
   const float sl = p.scale_log2e;
   const int n_tiles = (p.Nk + KT - 1) / KT;
 
@@ -191,60 +203,73 @@ k_flash_attn_fwd(const Params p) {
     const int buf = t & 1;
     if (t + 1 < n_tiles) issue_loads(t + 1);
 
-    // ---- S^T = K Q^T : two 32-key blocks x four 16-wide d steps ---------------------------------------------------
-    f32x16 s[2];
+    // ---- S^T = K Q^T : two 32-key blocks x four 16-wide d steps (each K fragment feeds all QN query blocks) ---------
+    f32x16 s[QN][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
+    for (int qn = 0; qn < QN; ++qn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[qn][0][i] = s[qn][1][i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {  // the two accumulator chains alternate: no back-to-back dependent MFMAs
+      for (int kb = 0; kb < 2; ++kb) {  // the accumulator chains alternate: no back-to-back dependent MFMAs
         const Vec16 kf = *reinterpret_cast<const Vec16*>(&sm.k[buf][(32 * kb + ln) * K_LD + 16 * ks + 8 * hi]);
-        s[kb] = T::mfma(as_v8<typename T::v8>(kf), qf[ks], s[kb]);
+#pragma unroll
+        for (int qn = 0; qn < QN; ++qn) s[qn][kb] = T::mfma(as_v8<typename T::v8>(kf), qf[qn][ks], s[qn][kb]);
       }
-    // s[kb][r] = score of key 32 kb + 8 (r>>2) + 4 hi + (r&3) against this lane's query row
+    // s[qn][kb][r] = score of key 32 kb + 8 (r>>2) + 4 hi + (r&3) against this lane's query row of block qn
     if ((t + 1) * KT > p.Nk) {  // ragged last tile: keys past Nk contribute nothing
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (t * KT + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
+          if (t * KT + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3) >= p.Nk) {
+#pragma unroll
+            for (int qn = 0; qn < QN; ++qn) s[qn][kb][r] = -INFINITY;
+          }
     }
 
     // ---- online softmax (the two lanes of a query row, hi = 0/1, hold disjoint halves of its keys) ----------------
-    float mx = s[0][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+    for (int qn = 0; qn < QN; ++qn) {
+      float mx = s[qn][0][0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float mb = m_new * sl;
-    const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, sl, -mb));  // exp2(-inf) = 0 on the first tile
-    m_run = m_new;
-    float psum = 0.f;
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qn][0][r]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qn][1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qn], mx);
+      const float mb = m_new * sl;
+      const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run[qn], sl, -mb));  // exp2(-inf) = 0 on the first tile
+      m_run[qn] = m_new;
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl, -mb));
-        s[kb][r] = e;
-        psum += e;
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qn][kb][r], sl, -mb));
+          s[qn][kb][r] = e;
+          psum += e;
+        }
+      l_run[qn] = __builtin_fmaf(l_run[qn], alpha, psum);  // per-lane partial; the two halves are added once, at the end
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        oacc[qn][0][i] *= alpha;
+        oacc[qn][1][i] *= alpha;
       }
-    l_run = __builtin_fmaf(l_run, alpha, psum);  // per-lane partial; the two halves are added once, at the end
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      oacc[0][i] *= alpha;
-      oacc[1][i] *= alpha;
     }
 
-    // ---- O^T += V^T P^T : four 16-key steps x two 32-wide d blocks -------------------------------------------------
+    // ---- O^T += V^T P^T : four 16-key steps x two 32-wide d blocks (each V fragment feeds all QN query blocks) ------
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      f32x8 pv;
+      typename T::v8 pf[QN];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pv[j] = s[st >> 1][8 * (st & 1) + j];
-      const typename T::v8 pf = T::pack(pv);  // B operand: slot j <-> key 16 st + 8 (j>>2) + 4 hi + (j&3)
+      for (int qn = 0; qn < QN; ++qn) {
+        f32x8 pv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = s[qn][st >> 1][8 * (st & 1) + j];
+        pf[qn] = T::pack(pv);  // B operand: slot j <-> key 16 st + 8 (j>>2) + 4 hi + (j&3)
+      }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         Vec16 vf;
@@ -264,7 +289,8 @@ k_flash_attn_fwd(const Params p) {
           const Vec8 hi8 = *reinterpret_cast<const Vec8*>(vrow + 8);
           vf.w[0] = lo.w[0], vf.w[1] = lo.w[1], vf.w[2] = hi8.w[0], vf.w[3] = hi8.w[1];
         }
-        oacc[db] = T::mfma(as_v8<typename T::v8>(vf), pf, oacc[db]);
+#pragma unroll
+        for (int qn = 0; qn < QN; ++qn) oacc[qn][db] = T::mfma(as_v8<typename T::v8>(vf), pf[qn], oacc[qn][db]);
       }
     }
 
@@ -273,21 +299,24 @@ k_flash_attn_fwd(const Params p) {
   }
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ; lane holds d = 32 db + 8 (r>>2) + 4 hi + (r&3) of its query row ----------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (q_row < p.Nq) {
-    uint16_t* orow = og + (int64_t)q_row * p.o_sn;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int qn = 0; qn < QN; ++qn) {
+    const float l_tot = l_run[qn] + __shfl_xor(l_run[qn], 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row[qn] < p.Nq) {
+      uint16_t* orow = og + (int64_t)q_row[qn] * p.o_sn;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x8 tmp;
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tmp[e] = oacc[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
-        const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
-        Vec8 out8 = {{packed.w[0], packed.w[1]}};
-        *reinterpret_cast<Vec8*>(orow + 32 * db + 8 * g + 4 * hi) = out8;
-      }
+        for (int g = 0; g < 4; ++g) {
+          f32x8 tmp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tmp[e] = oacc[qn][db][4 * g + e] * inv, tmp[4 + e] = 0.f;
+          const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
+          Vec8 out8 = {{packed.w[0], packed.w[1]}};
+          *reinterpret_cast<Vec8*>(orow + 32 * db + 8 * g + 4 * hi) = out8;
+        }
+    }
   }
 }
 
@@ -304,22 +333,29 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   if ((q_sb | q_sn | k_sb | k_sn | v_sb | v_sn) % 8 || (o_sb | o_sn) % 4) return (int)hipErrorInvalidValue;
   Params p;
   p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
-  p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + QB - 1) / QB;
+  // v_path: bit 0 = V staging path (0 transpose-read, 1 V^T tile); bit 1 = 64 query rows per wave (256 per workgroup)
+  const int qn = (v_path & 2) ? 2 : 1;
+  p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + QB * qn - 1) / (QB * qn);
   p.q_sb = q_sb, p.q_sn = q_sn, p.k_sb = k_sb, p.k_sn = k_sn, p.v_sb = v_sb, p.v_sn = v_sn, p.o_sb = o_sb, p.o_sn = o_sn;
   p.scale_log2e = scale * 1.44269504088896340736f;
   const int64_t blocks = (int64_t)p.BH * p.nqb;
   if (blocks > 0x7fffffff) return (int)hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(256);
   hipStream_t st = (hipStream_t)stream;
+#define ED_FA(T)                                                                 \
+  if (v_path == 0) k_flash_attn_fwd<T, true, 1><<<grid, block, 0, st>>>(p);      \
+  else if (v_path == 1) k_flash_attn_fwd<T, false, 1><<<grid, block, 0, st>>>(p); \
+  else if (v_path == 2) k_flash_attn_fwd<T, true, 2><<<grid, block, 0, st>>>(p);  \
+  else if (v_path == 3) k_flash_attn_fwd<T, false, 2><<<grid, block, 0, st>>>(p); \
+  else return (int)hipErrorInvalidValue;
   if (dtype == ED_BF16) {
-    if (v_path == 0) k_flash_attn_fwd<BF, true><<<grid, block, 0, st>>>(p);
-    else k_flash_attn_fwd<BF, false><<<grid, block, 0, st>>>(p);
+    ED_FA(BF)
   } else if (dtype == ED_F16) {
-    if (v_path == 0) k_flash_attn_fwd<HF, true><<<grid, block, 0, st>>>(p);
-    else k_flash_attn_fwd<HF, false><<<grid, block, 0, st>>>(p);
+    ED_FA(HF)
   } else {
     return (int)hipErrorInvalidValue;
   }
+#undef ED_FA
   return (int)hipGetLastError();
 }
 

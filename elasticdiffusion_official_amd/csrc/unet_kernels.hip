@@ -407,38 +407,57 @@ __global__ void k_gn_nhwc_finalize(const float* __restrict__ partial, float* __r
   stats[2 * t + 1] = rsqrtf((float)var + eps);
 }
 
+// Same thread <-> column mapping as the statistics kernel: gamma / beta / folded biases / the (at most two) group statistics of
+// a thread's 8 channels are loaded ONCE, then it streams rows: one 16-byte load and one 16-byte store per item, no integer
+// division in the loop.  (The first version was a flat pass with per-item 64-bit div/mod and five side loads per vector:
+// 2.3 TB/s.)
 template <typename T, bool ACT>
 __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
-                const float* __restrict__ stats, uint16_t* __restrict__ out, int C, int HW, int G, int64_t total_vec) {
-  const bool has_cb = chan_bias != nullptr, has_kb = conv_bias != nullptr;
+                const float* __restrict__ stats, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block) {
+  const int n = blockIdx.y, chunk = blockIdx.x;
   const int VC = C >> 3, cpg = C / G;
-  for (int64_t t = (int64_t)blockIdx.x * GNL_THREADS + threadIdx.x; t < total_vec; t += (int64_t)gridDim.x * GNL_THREADS) {
-    int vc = (int)(t % VC);
-    int64_t np = t / VC;
-    int n = (int)(np / HW);
-    int c0 = vc << 3;
-    U16x8 v = *reinterpret_cast<const U16x8*>(x + t * 8);
-    U16x8 gm = *reinterpret_cast<const U16x8*>(gamma + c0);
-    U16x8 bt = *reinterpret_cast<const U16x8*>(beta + c0);
-    U16x8 kbv, cbv;
-    if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
-    if (has_cb) cbv = *reinterpret_cast<const U16x8*>(chan_bias + (int64_t)n * C + c0);
-    U16x8 o;
+  const int ncol = (VC + GNL_THREADS - 1) / GNL_THREADS;
+  const int R = ncol == 1 ? GNL_THREADS / VC : 1;
+  const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
+  const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
+  if (ncol == 1 && (int)threadIdx.x >= R * VC) return;
+  const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  const bool has_cb = chan_bias != nullptr, has_kb = conv_bias != nullptr;
+  const uint16_t* xb = x + (int64_t)n * HW * C;
+  uint16_t* ob = out + (int64_t)n * HW * C;
+#pragma unroll
+  for (int j = 0; j < GNL_MAXCOL; ++j) {
+    const int vc = my_c + j * GNL_THREADS;
+    if (j >= ncol || vc >= VC) break;
+    const int c0 = vc << 3;
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;  // C/G >= 8: a vector touches at most two groups
     const float mean0 = stats[2 * (n * G + g0)], rstd0 = stats[2 * (n * G + g0) + 1];
     const float mean1 = split < 8 ? stats[2 * (n * G + g0 + 1)] : 0.f, rstd1 = split < 8 ? stats[2 * (n * G + g0 + 1) + 1] : 0.f;
+    const U16x8 gm = *reinterpret_cast<const U16x8*>(gamma + c0), bt = *reinterpret_cast<const U16x8*>(beta + c0);
+    U16x8 kbv, cbv;
+    if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
+    if (has_cb) cbv = *reinterpret_cast<const U16x8*>(chan_bias + (int64_t)n * C + c0);
+    float a[8], b[8], kb[8], cb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float mean = e < split ? mean0 : mean1, rstd = e < split ? rstd0 : rstd1;
-      float a = rstd * T::to_f32(gm.v[e]);
-      float b = fmaf(-a, mean, T::to_f32(bt.v[e]));
-      float xin = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
-      float y = T::to_f32(T::from_f32(fmaf(a, xin, b)));
-      o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+      a[e] = rstd * T::to_f32(gm.v[e]);
+      b[e] = fmaf(-a[e], mean, T::to_f32(bt.v[e]));
+      kb[e] = has_kb ? T::to_f32(kbv.v[e]) : 0.f;
+      cb[e] = has_cb ? T::to_f32(cbv.v[e]) : 0.f;
     }
-    *reinterpret_cast<U16x8*>(out + t * 8) = o;
+    for (int row = r0 + my_r; row < r1; row += R) {
+      const int64_t off = (int64_t)row * C + c0;
+      U16x8 v = *reinterpret_cast<const U16x8*>(xb + off), o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = T::to_f32(T::from_f32(fmaf(a[e], biased<T>(v.v[e], kb[e], has_kb, cb[e], has_cb), b[e])));
+        o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+      }
+      *reinterpret_cast<U16x8*>(ob + off) = o;
+    }
   }
 }
 
@@ -619,9 +638,10 @@ __global__ void __launch_bounds__(256)
 k_bias_residual_add(const uint16_t* __restrict__ h, const uint16_t* __restrict__ hb, const uint16_t* __restrict__ res,
                     const uint16_t* __restrict__ rb, uint16_t* __restrict__ out, int C, int HW, int64_t total_vec,
                     int channels_last) {
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total_vec; t += (int64_t)gridDim.x * 256) {
+  const uint32_t HW8 = (uint32_t)HW >> 3, VC = (uint32_t)C >> 3;  // total_vec < 2^31 (checked on the host): 32-bit math
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < (uint32_t)total_vec; t += gridDim.x * 256u) {
     // NCHW: the 8 elements share one channel (HW % 8 == 0); channels-last: they are 8 consecutive channels (C % 8 == 0)
-    const int c = channels_last ? (int)((t * 8) % C) : (int)((t * 8 / HW) % C);
+    const int c = channels_last ? (int)((t % VC) << 3) : (int)((t / HW8) % (uint32_t)C);
     float b1[8], b2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -629,7 +649,8 @@ k_bias_residual_add(const uint16_t* __restrict__ h, const uint16_t* __restrict__
       b1[e] = hb ? T::to_f32(hb[ce]) : 0.f;
       b2[e] = rb ? T::to_f32(rb[ce]) : 0.f;
     }
-    U16x8 hv = *reinterpret_cast<const U16x8*>(h + t * 8), rv = *reinterpret_cast<const U16x8*>(res + t * 8), o;
+    const int64_t off = (int64_t)t * 8;
+    U16x8 hv = *reinterpret_cast<const U16x8*>(h + off), rv = *reinterpret_cast<const U16x8*>(res + off), o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = T::to_f32(hv.v[e]), r = T::to_f32(rv.v[e]);
@@ -637,7 +658,7 @@ k_bias_residual_add(const uint16_t* __restrict__ h, const uint16_t* __restrict__
       if (rb) r = T::to_f32(T::from_f32(r + b2[e]));
       o.v[e] = T::from_f32(r + a);
     }
-    *reinterpret_cast<U16x8*>(out + t * 8) = o;
+    *reinterpret_cast<U16x8*>(out + off) = o;
   }
 }
 
@@ -753,21 +774,21 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
   dim3 grid1(nchunks, N);
   const int VC_ = C / 8;
   size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= GNL_THREADS ? GNL_THREADS / VC_ : 1);
-  int64_t total_vec = (int64_t)N * HW * (C / 8);
-  int grid3 = (int)((total_vec + GNL_THREADS - 1) / GNL_THREADS < 8192 ? (total_vec + GNL_THREADS - 1) / GNL_THREADS : 8192);
   int NG = N * G;
 #define GNL_RUN(T)                                                                                                     \
   k_gn_nhwc_partial<T><<<grid1, GNL_THREADS, lds, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                \
                                                        (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
   k_gn_nhwc_finalize<<<(NG + 127) / 128, 128, 0, s>>>(partial, stats, G, nchunks, (double)HW * (C / G), eps, NG);      \
   if (act_silu)                                                                                                        \
-    k_gn_nhwc_apply<T, true><<<grid3, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
+    k_gn_nhwc_apply<T, true><<<grid1, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
                                                           (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
-                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, total_vec); \
+                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, \
+                                                          rows_per_block);                                             \
   else                                                                                                                 \
-    k_gn_nhwc_apply<T, false><<<grid3, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                \
+    k_gn_nhwc_apply<T, false><<<grid1, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                \
                                                            (const uint16_t*)beta, (const uint16_t*)conv_bias,          \
-                                                           (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, total_vec);
+                                                           (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, \
+                                                           rows_per_block);
   if (dtype == ED_BF16) {
     GNL_RUN(BF16)
   } else if (dtype == ED_F16) {
@@ -827,7 +848,8 @@ int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, con
   if ((channels_last ? C % 8 : HW % 8) != 0 || (((uintptr_t)h | (uintptr_t)res | (uintptr_t)out) & 15u))
     return (int)hipErrorInvalidValue;
   int64_t total_vec = (int64_t)N * C * HW / 8;
-  int grid = (int)((total_vec + 255) / 256 < 8192 ? (total_vec + 255) / 256 : 8192);
+  if (total_vec >= 0x7fffffff) return (int)hipErrorInvalidValue;
+  int grid = (int)((total_vec + 255) / 256 < 16384 ? (total_vec + 255) / 256 : 16384);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == ED_BF16)
     k_bias_residual_add<BF16><<<grid, 256, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,

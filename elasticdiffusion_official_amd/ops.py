@@ -399,10 +399,14 @@ def bias_residual_add(h, h_bias, res, res_bias=None):
     or both channels_last (ResnetBlock2D's closing add); the result has the same memory format."""
     N, C, H, W = h.shape
     assert res.shape == h.shape and res.dtype == h.dtype
-    cl = (not h.is_contiguous()) and h.is_contiguous(memory_format=torch.channels_last)
+    if not (h.is_cuda and res.is_cuda):
+        _reject("bias_residual_add: h and res must be tensors on the MI355X; no CPU fallback")
+    cl = (not h.is_contiguous()) and h.is_contiguous(memory_format=torch.channels_last) and C % 8 == 0
     fmt = torch.channels_last if cl else torch.contiguous_format
-    if not (h.is_cuda and res.is_cuda and h.is_contiguous(memory_format=fmt) and res.is_contiguous(memory_format=fmt)):
-        _reject("bias_residual_add: h and res must be MI355X tensors in the same (NCHW or channels_last) dense format")
+    # mixed layouts only arise on fallback paths (a torch GroupNorm returning NCHW inside a channels-last model): follow
+    # the convolution output's layout, re-laying-out the other operand
+    h = h.contiguous(memory_format=fmt)
+    res = res.contiguous(memory_format=fmt)
     out = torch.empty_like(h, memory_format=fmt)
     TIMER.note_work("ed_bias_residual_add", nbytes=3.0 * h.numel() * h.element_size())
     _call("ed_bias_residual_add", h.data_ptr(), _opt(h_bias, h.dtype, "h_bias"), res.data_ptr(),
@@ -421,7 +425,17 @@ def tokens_add_nchw(x, tokens):
     return out
 
 
-FLASH_V_PATH = 0  # 0 = ds_read_b64_tr_b16 from a row-major V tile, 1 = V^T tile in LDS (A/B switch, same results)
+# kernel variant (identical results): bit 0 = V staging (0: ds_read_b64_tr_b16 from a row-major V tile, 1: V^T tile in
+# LDS); bit 1 = 64 query rows per wave (256 per workgroup) instead of 32.  None = choose per shape: the 64-row variant is
+# faster only when there is enough work to fill the chip with half as many workgroups (measured, batch 20: N=4096
+# 848 vs 776 TFLOP/s; N=1024 and the 77-key cross attention: no gain or slower; profiles/r2_s7_probe_attn.jsonl)
+FLASH_V_PATH = None
+
+
+def _flash_variant(B, heads, Nq, Nk):
+    if FLASH_V_PATH is not None:
+        return int(FLASH_V_PATH)
+    return 2 if (Nq >= 2048 and Nk >= 1024 and B * heads * (Nq // 256) >= 1024) else 0
 
 
 def flash_attention(q, k, v, heads, v_path=None):
@@ -445,5 +459,5 @@ def flash_attention(q, k, v, heads, v_path=None):
                     nbytes=2.0 * q.element_size() * HD * B * (Nq + Nk))
     _call("ed_flash_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _code(q, "q"), B, heads, Nq, Nk,
           64, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
-          0.125, FLASH_V_PATH if v_path is None else int(v_path), _stream())
+          0.125, _flash_variant(B, heads, Nq, Nk) if v_path is None else int(v_path), _stream())
     return out

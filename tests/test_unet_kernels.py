@@ -195,7 +195,7 @@ def _attn_ref(q, k, v, H):
     return (torch.softmax(s, dim=-1) @ vf).transpose(1, 2).reshape(B, Nq, HD)
 
 
-@pytest.mark.parametrize("v_path", [0, 1])
+@pytest.mark.parametrize("v_path", [0, 1, 2, 3])  # bit 0: V staging path; bit 1: 64 query rows per wave
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 10, 4096, 4096), (3, 20, 1024, 1024), (2, 20, 1024, 77), (1, 10, 4096, 77),
                                        (2, 2, 256, 256), (1, 4, 64, 64), (1, 1, 100, 77), (2, 3, 200, 333), (1, 2, 1, 1)])
@@ -234,9 +234,9 @@ def test_flash_attention_strided_inputs_and_outlier_rows():
     assert float((got.float() - ref).abs().max()) < 3e-2
     assert float((got[0, 5, :64].float() - v[0, 600, :64].float()).abs().max()) < 3e-2   # ~one-hot row
     assert float((got[1, 7].float() - v[1].float().mean(0)).abs().max()) < 2e-2          # ~mean of V
-    for path in (0, 1):
+    for path in (0, 1, 2, 3):
         again = ops.flash_attention(q.contiguous(), k.contiguous(), v.contiguous(), H, v_path=path)
-        assert torch.equal(again, got)  # strides and the V staging path do not change a single bit
+        assert torch.equal(again, got)  # strides, the V staging path and the rows-per-wave variant do not change a bit
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

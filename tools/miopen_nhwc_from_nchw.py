@@ -70,3 +70,74 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Second step: perf-db records for conv problems that were never tuned.
+#
+# Measured (gpurun session 7, profiles/r2_s7_*): for a channels-last bf16 problem MIOpen's immediate mode runs the CK
+# grouped-conv solver whether or not the user find-db ranks it first; WITH a perf-db record it runs the tuned instance
+# (0.8 ms on 320->320 3x3 at batch 20), WITHOUT one a default instance that is ~40x slower (33.9 ms per call at batch 32:
+# 1.26 s of a 1.49 s forward).  The tuned instances exist only for the batch sizes a find pass was run at (20, 6, 10, 3).
+# A CK instance is a GEMM tile configuration; the implicit-GEMM dimensions it tiles are M = N*Ho*Wo, N = Cout,
+# K = Cin*kh*kw, so the instance tuned for one batch size of a convolution is a sound (if not provably optimal) choice for
+# the same convolution at another batch size, and -- one step further -- for the same (Cin, Cout, kernel, stride) at another
+# spatial size.  This writes such borrowed records for every bf16 problem in the find-db that has none, and for a grid of
+# batch sizes (the per-rank batches of row sharding and of several images in flight) of every UNet convolution shape.
+# ---------------------------------------------------------------------------------------------------------------------
+EXTRA_BATCHES = (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 16, 18, 20, 24, 26, 32, 36, 40, 52)
+
+
+def _parse_udb_key(k):
+    f = k.split("x")
+    # [2, Cin, H, W, 1, kh, kw, 1, Cout, N, ph, pw, pd, sh, sw, sd, dh, dw, dd, bias, group, layout, dtype, dir]
+    return dict(cin=int(f[1]), H=int(f[2]), W=int(f[3]), kh=int(f[5]), kw=int(f[6]), cout=int(f[8]), n=int(f[9]),
+                pad=(f[10], f[11]), stride=(f[13], f[14]), layout=f[21], dtype=f[22], fields=f)
+
+
+def borrow_ck_instances():
+    udb_path = glob.glob(os.path.join(CACHE, "*.udb.txt"))[0]
+    ufdb_path = glob.glob(os.path.join(CACHE, "*.ufdb.txt"))[0]
+    udb, ufdb = read(udb_path), read(ufdb_path)
+    donors = {}  # (cin, cout, kh, kw, stride, pad) -> list of (H, W, n, instance)
+    for k, v in udb.items():
+        if "xBF16xF" not in k:
+            continue
+        p = _parse_udb_key(k)
+        inst = [r for r in v.split(";") if r.startswith(CK + ":")]
+        if inst:
+            donors.setdefault((p["cin"], p["cout"], p["kh"], p["kw"], p["stride"], p["pad"]), []).append(
+                (p["H"], p["W"], p["n"], inst[0]))
+    # every distinct bf16 convolution shape the find-db has seen (either layout, any batch)
+    shapes = set()
+    for k in ufdb:
+        if not k.endswith("-BF16-F"):
+            continue
+        f = k.split("-")
+        cin, H, W, kk, cout, Ho, Wo, n, pad, stride = f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]
+        kh, kw = kk.split("x")
+        shapes.add((int(cin), int(H), int(W), int(kh), int(kw), int(cout), tuple(pad.split("x")), tuple(stride.split("x")),
+                    int(n)))
+    base = {s[:-1] for s in shapes}
+    want = {s for s in shapes} | {b + (n,) for b in base for n in EXTRA_BATCHES}
+    added = 0
+    for (cin, H, W, kh, kw, cout, pad, stride, n) in sorted(want):
+        cand = donors.get((cin, cout, kh, kw, stride, pad))
+        if not cand:
+            continue
+        # same spatial size first, then nearest batch
+        inst = min(cand, key=lambda c: ((c[0], c[1]) != (H, W), abs(c[0] * c[1] - H * W), abs(c[2] - n)))[3]
+        for layout in ("NHWC", "NCHW"):
+            key = "x".join(str(v) for v in (2, cin, H, W, 1, kh, kw, 1, cout, n, pad[0], pad[1], 0, stride[0], stride[1], 0,
+                                            1, 1, 0, 0, 1, layout, "BF16", "F"))
+            cur = udb.get(key, "")
+            if (CK + ":") in cur:
+                continue
+            udb[key] = (cur + ";" if cur else "") + inst
+            added += 1
+    write(udb_path, udb)
+    print(f"{added} borrowed CK perf-db records written ({len(udb)} records in total)")
+
+
+if __name__ == "__main__":
+    borrow_ck_instances()

@@ -47,7 +47,7 @@ def probe_attn():
         flops = 4.0 * B * H * Nq * Nk * 64
         t_sdpa = ev_time(lambda: F.scaled_dot_product_attention(q4, k4, v4))
         res = {"B": B, "H": H, "Nq": Nq, "Nk": Nk, "sdpa_us": round(t_sdpa, 1), "sdpa_tflops": round(flops / t_sdpa / 1e6, 1)}
-        for path in (0, 1):
+        for path in (0, 1, 2):
             t = ev_time(lambda: ops.flash_attention(q, k, v, H, v_path=path))
             res[f"flash{path}_us"] = round(t, 1)
             res[f"flash{path}_tflops"] = round(flops / t / 1e6, 1)
@@ -127,9 +127,9 @@ def probe_unet(unet, cfg):
         res["all_off_ms"] = round(ev_time(fwd, reps=3, warm=1) / 1e3, 2)
         for n in names:
             setattr(M, n, True)
-        ops.FLASH_V_PATH = 1
-        res["flash_vpath1_ms"] = round(ev_time(fwd, reps=3, warm=1) / 1e3, 2)
         ops.FLASH_V_PATH = 0
+        res["flash_variant0_ms"] = round(ev_time(fwd, reps=3, warm=1) / 1e3, 2)
+        ops.FLASH_V_PATH = None
         emit(probe="unet", **res)
 
 
