@@ -10,6 +10,10 @@ below is computed with the SAME expressions the kernel uses, under the documente
                         row (i>>2), columns 4*(i&3).. of a [4][16] block; lane i receives column i (4 rows).
 
     python tools/emulate_flash_attention.py        -> prints max |err| for both V paths, ragged Nq / Nk included
+
+(The 64-rows-per-wave variant of the kernel, QN = 2, runs the same per-row arithmetic on two 32-row query blocks with
+shared K / V fragments; only ``q_row = qblk * 128 * QN + (wave * QN + qn) * 32 + lane % 32`` differs.  The GPU test
+checks it bit for bit against the QN = 1 variant emulated here.)
 """
 import numpy as np
 
