@@ -218,3 +218,59 @@ def test_pick_sampler_draws_equal_oracle_chain(h, w, K, seed):
     for k in range(K):
         ref[torch.arange(N), want[k]] = k
     assert torch.equal(stamp, ref)
+
+
+def test_make_grid_matches_torchvision_layout():
+    """pipeline._make_grid == torchvision.utils.make_grid(imgs, nrow=8, padding=2, pad_value=0) (what ED:1124 calls)."""
+    import torch
+    from elasticdiffusion_official_amd.pipeline import _make_grid
+    one = torch.rand(1, 3, 5, 7)
+    assert torch.equal(_make_grid(one), one[0])                       # a single image passes through
+    imgs = torch.rand(10, 3, 4, 6)
+    g = _make_grid(imgs)
+    assert g.shape == (3, 2 * (4 + 2) + 2, 8 * (6 + 2) + 2)           # 8 per row, 2 rows, 2-px frame and separators
+    assert torch.equal(g[:, 2:6, 2:8], imgs[0]) and torch.equal(g[:, 2:6, 10:16], imgs[1])
+    assert torch.equal(g[:, 8:12, 2:8], imgs[8]) and float(g[:, :2].abs().sum()) == 0.0
+    assert float(g[:, 8:12, 18:].abs().sum()) == 0.0                  # the unused cells of the last row stay zero
+
+
+def test_flash_variant_heuristic():
+    from elasticdiffusion_official_amd import ops
+    assert ops._flash_variant(20, 10, 4096, 4096) == 2   # SDXL level-2 self attention at batch 20: 64 rows per wave
+    assert ops._flash_variant(20, 20, 1024, 1024) == 0   # level 3
+    assert ops._flash_variant(20, 10, 4096, 77) == 0     # cross attention
+    assert ops._flash_variant(1, 10, 4096, 4096) == 0    # too few workgroups to fill the chip with 256-row blocks
+    saved = ops.FLASH_V_PATH
+    try:
+        ops.FLASH_V_PATH = 1
+        assert ops._flash_variant(20, 10, 4096, 4096) == 1
+    finally:
+        ops.FLASH_V_PATH = saved
+
+
+def test_miopen_db_derivation_is_idempotent_and_well_formed(tmp_path):
+    """tools/miopen_nhwc_from_nchw.py on a copy of the in-tree db: running it twice changes nothing, every NHWC perf-db
+    key has its NCHW twin's CK instance, and borrowed records exist for the untuned batch sizes of the UNet shapes."""
+    import glob
+    import importlib.util
+    import os
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = os.path.join(tmp_path, "miopen_cache")
+    shutil.copytree(os.path.join(root, "miopen_cache"), work)
+    spec = importlib.util.spec_from_file_location("nhwc_tool", os.path.join(root, "tools", "miopen_nhwc_from_nchw.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    tool.CACHE = work
+    tool.main()
+    tool.borrow_ck_instances()
+    snap = {f: open(f).read() for f in glob.glob(os.path.join(work, "*.txt"))}
+    tool.main()
+    tool.borrow_ck_instances()
+    assert all(open(f).read() == s for f, s in snap.items())
+    udb = tool.read(glob.glob(os.path.join(work, "*.udb.txt"))[0])
+    k20 = "2x320x128x128x1x3x3x1x320x20x1x1x0x1x1x0x1x1x0x0x1x{}xBF16xF"
+    inst = [r for r in udb[k20.format("NCHW")].split(";") if r.startswith(tool.CK)][0]
+    assert inst in udb[k20.format("NHWC")]
+    assert inst in udb[k20.format("NHWC").replace("x320x20x", "x320x32x")]      # borrowed for cfg4's batch 32
+    assert tool.CK in udb["2x320x64x64x1x3x3x1x320x20x1x1x0x1x1x0x1x1x0x0x1xNHWCxBF16xF"]  # SD1.5 shape
