@@ -13,8 +13,12 @@
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); NULL = default stream;
  *   - "dtype" arguments: ED_F32 / ED_F16 / ED_BF16 select the element type of the buffer crossing the torch model
  *     boundary (UNet / VAE / ControlNet tensors).  All latent-space state is fp32;
- *   - arithmetic is fp32 with contraction disabled, in the operation order of the reference's torch-CPU path, so
- *     results are bit-identical to it for fp32 model tensors;
+ *   - latent-space glue entry points (everything up to ed_tile_accumulate_normalise, ed_assemble_rows,
+ *     ed_phase_epilogue): arithmetic is fp32 with contraction disabled, in the operation order of the reference's
+ *     torch-CPU path, so results are bit-identical to it for fp32 model tensors;
+ *   - entry points inside the UNet (ed_geglu .. ed_flash_attention): 16-bit tensors, fp32 math, every value rounded to
+ *     the 16-bit type where the torch kernel it replaces rounds; ed_flash_attention accumulates in fp32 on the MFMA
+ *     units and rounds the softmax probabilities to the I/O type before the second contraction;
  *   - re-entrant, stateless; one host thread per process, one process per GPU.
  */
 #ifndef ELASTIC_HIP_H
