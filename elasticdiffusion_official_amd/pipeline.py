@@ -1,19 +1,20 @@
 """MI355X-native drop-in for the hot path of the reference's ``ElasticDiffusion`` class
 (/root/reference/elastic_diffusion.py:110-1130, "ED:n" below; ControlNet variant "EDC:n" =
 elastic_diffusion_w_controlnet.py): same constructor and ``generate_image`` surface, same RNG stream as the
-reference's CPU path, but one timestep is
+reference's CPU path, but one image is a *program* (a generator, ``_program``) whose timestep is
 
     host   : pick-index draws (torch CPU generator, ED:501-544) + pad-strip reseed replay (ED:359)   -- no device sync
-    HIP    : ed_pick_assemble + ed_gather_views   -> ONE model-input batch: K CFG pairs + V views (all d x d)
-    torch  : ONE UNet forward for the whole batch (rows optionally sharded over ranks, all-gathered over RCCL)
-    HIP    : ed_unpad_direction, ed_fill_directions, ed_scatter_centres, ed_cfg_ddim_step
+    HIP    : ed_assemble_rows       -> ONE model-input batch: K CFG pairs + V views (all d x d)
+    yield  : ONE UNet forward for the whole batch (hipGraph replay; rows optionally sharded over ranks and all-gathered
+             over RCCL; with several images in flight the rows of all pending calls are fused, per-row timesteps)
+    HIP    : ed_phase_epilogue      -> unpad, fill, scatter, CFG + DDIM [, RRG] in one launch
     HIP    : [RePaint] ed_undo_step, then the same phase with K = 1 and guidance/3
-    HIP    : [RRG] ed_rrg_update
 
 instead of the reference's R+1 sequential batch-2 UNet calls, V/view_batch_size view calls and ~hundreds of eager
 tensor ops with host syncs per step.  The resampling steps can be batched because their inputs depend only on the RNG,
 never on each other's UNet outputs (ED:661-681): the sequential semantics live only in the overwrite order of the
-fill, which ed_fill_directions reproduces.
+fill, which the epilogue's per-pixel last-covering-step table reproduces.  (``FUSED_GLUE = False`` runs the same steps
+through the separate entry points ed_pick_assemble ... ed_rrg_update.)
 
 There is no CPU path in this module: without the HIP library and a ROCm device it raises.
 """
