@@ -35,6 +35,13 @@ from .sharding import RowSharder
 # per phase instead of 6-7.  False = the separate entry points (kept for A/B and for the per-kernel parity tests).
 FUSED_GLUE = True
 
+# Experiment switch (default off): compute the pad-strip frames (100 fp32 VAE encodes per SDXL 1024x2048 image, 1.16 s) on
+# a side stream in chunks of timesteps while the denoising loop already runs, the loop waiting stream-side for the chunk
+# that holds the timestep it is about to use.  Measured on the MI355X (gpurun session 12, bench.py --steps 2): 12.73 vs
+# 12.79 s per image -- the UNet already saturates the chip, the VAE kernels only interleave with it -- so the simpler
+# compute-before-the-loop order stays the default.  Single rank only (with row sharding the encodes contain a collective).
+ASYNC_STRIPS = __import__("os").environ.get("ED_ASYNC_STRIPS", "0") == "1"
+
 
 def _identity_progress(it):
     return it
@@ -199,6 +206,8 @@ class ElasticDiffusion(nn.Module):
         # default so that every image pays for its own frames.
         self.cache_backgrounds = cache_backgrounds
         self._frame_cache = {}
+        self._frame_events = {}   # id(frames) -> [(first timestep, event)] of side-stream chunks not yet waited for
+        self._vae_stream = None
         # one hipGraph per model batch shape (graphs.py); falls back to eager launches if a capture fails
         self._runner = GraphedForward(self._forward_rows, enabled=use_graphs)
         self._time_ids = torch.zeros(1, 6, dtype=torch.float32, device=device)  # persistent: captured by the graphs
@@ -304,49 +313,80 @@ class ElasticDiffusion(nn.Module):
         return P
 
     @torch.no_grad()
-    def _strip_frames(self, pad, timesteps, C):
+    def _strip_frames(self, pad, timesteps, C, overlap=False):
         """All noised-background frames [T,C,PH,PW] of one PadPlan (ED:327-391), computed once per image instead of
         2 VAE encodes per global UNet call (the reference's TODO at ED:340).  Contents depend only on
-        (dim, side, size, t); the draws come from md5-seeded private generators (host_rng.strip_draws)."""
+        (dim, side, size, t); the draws come from md5-seeded private generators (host_rng.strip_draws).
+        ``overlap``: enqueue the work on the side stream and register per-chunk events (``_await_frames``)."""
         T = len(timesteps)
         if not pad.padded:
             return None
         key = (pad.h, pad.w, pad.d, C, tuple(int(t) for t in timesteps))
         if self.cache_backgrounds and key in self._frame_cache:
             return self._frame_cache[key]
-        frames = torch.zeros(T, C, pad.PH, pad.PW, device=self.device, dtype=torch.float32)
+        dev = self.device
+        frames = torch.zeros(T, C, pad.PH, pad.PW, device=dev, dtype=torch.float32)
         sf = self.vae.config.scaling_factor
         s = self.vae_scale_factor
         vae_dtype = next(self.vae.parameters()).dtype
-        for (dim, side, Hs, Ws, y0, x0) in pad.strips:
-            draws = [host_rng.strip_draws(dim, side, Hs, Ws, t, C) for t in timesteps]
-            colour = torch.cat([dr[0] for dr in draws]).to(self.device)
-            post = torch.cat([dr[1] for dr in draws]).to(self.device)
-            fwd = torch.cat([dr[2] for dr in draws]).to(self.device)
-            coef = torch.tensor([self.scheduler.add_noise_coefficients(t) for t in timesteps], dtype=torch.float32,
-                                device=self.device)
+        overlap = bool(overlap) and ASYNC_STRIPS and self.sharder.world_size == 1
+        main = torch.cuda.current_stream(dev)
+        if overlap:
+            if getattr(self, "_vae_stream", None) is None:
+                self._vae_stream = torch.cuda.Stream(device=dev)
+            side = self._vae_stream
+            side.wait_stream(main)  # the frames buffer (and the previous image's use of the VAE) come first
+        else:
+            side = main
+        coef_host = torch.tensor([self.scheduler.add_noise_coefficients(t) for t in timesteps], dtype=torch.float32)
+        plans = []
+        for (dim, side_id, Hs, Ws, y0, x0) in pad.strips:
+            draws = [host_rng.strip_draws(dim, side_id, Hs, Ws, t, C) for t in timesteps]
             # ~64 MiB of fp32 pixels per VAE call (SDXL: 21 strips); measured 1.17 s per image for the 100 strips vs
             # 1.77 s with one strip per call
             chunk = max(1, min(T, (64 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
+            plans.append((Hs, Ws, y0, x0, chunk, torch.cat([dr[0] for dr in draws]), torch.cat([dr[1] for dr in draws]),
+                          torch.cat([dr[2] for dr in draws])))
+        step = min(p[4] for p in plans)  # timesteps per chunk (strips of one PadPlan come in equal-sized pairs)
+        events = []
+        with torch.cuda.stream(side):
+            coef = coef_host.to(dev)
+            dev_plans = [(Hs, Ws, y0, x0, colour.to(dev), post.to(dev), fwd.to(dev))
+                         for (Hs, Ws, y0, x0, _, colour, post, fwd) in plans]
 
-            def encode(ix, *_):
-                """Noised strips of the timesteps ``ix`` (the VAE encodes are sharded over ranks like model rows)."""
-                outs = []
-                for a in range(0, ix.numel(), chunk):
-                    sel = ix[a:a + chunk]
-                    img = colour[sel][:, :, None, None].expand(sel.numel(), 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
+            def encode_range(Hs, Ws, colour, post, fwd):
+                def encode(ix, *_):
+                    """Noised strips of the timesteps ``ix`` (sharded over ranks like model rows)."""
+                    img = colour[ix][:, :, None, None].expand(ix.numel(), 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
                     dist = self.vae.encode(img).latent_dist
-                    enc = (dist.mean.float() + dist.std.float() * post[sel]) * sf
-                    cf = coef[sel]
-                    outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
-                return torch.cat(outs)
+                    enc = (dist.mean.float() + dist.std.float() * post[ix]) * sf
+                    cf = coef[ix]
+                    return cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[ix]
+                return encode
 
-            strips = self.sharder.run(encode, torch.arange(T, device=self.device), None, None, None,
-                                      out_like=((C, Hs, Ws), torch.float32))
-            frames[:, :, y0:y0 + Hs, x0:x0 + Ws] = strips
+            for a in range(0, T, step):
+                ix = torch.arange(a, min(T, a + step), device=dev)
+                for (Hs, Ws, y0, x0, colour, post, fwd) in dev_plans:
+                    strips = self.sharder.run(encode_range(Hs, Ws, colour, post, fwd), ix, None, None, None,
+                                              out_like=((C, Hs, Ws), torch.float32))
+                    frames[a:a + ix.numel(), :, y0:y0 + Hs, x0:x0 + Ws] = strips
+                if overlap:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append((a, ev))
+        if overlap:
+            self._frame_events[id(frames)] = events
         if self.cache_backgrounds:
             self._frame_cache[key] = frames
         return frames
+
+    def _await_frames(self, frames, ti):
+        """Make the current stream wait for the side-stream chunk(s) of ``frames`` that cover timestep ``ti``."""
+        evs = self._frame_events.get(id(frames)) if frames is not None else None
+        while evs and evs[0][0] <= ti:
+            torch.cuda.current_stream(self.device).wait_event(evs.pop(0)[1])
+        if evs is not None and not evs:
+            del self._frame_events[id(frames)]
 
     def _embed_rows(self, K, V, un, co, pun, pco):
         """Text rows for one fused model batch: K x [uncond(B), cond(B)] then V x uncond(B)  (ED:436-438, 846-847)."""
@@ -399,6 +439,8 @@ class ElasticDiffusion(nn.Module):
         if P.vpad.strips:
             for _ in range(math.ceil(P.views.V / self.view_batch_size)):
                 host_rng.replay_strip_reseeds(len(P.vpad.strips))
+        self._await_frames(self._gframes, ti)
+        self._await_frames(self._vframes, ti)
         gframe = None if self._gframes is None else self._gframes[ti]
         vframe = None if self._vframes is None else self._vframes[ti]
         low = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
@@ -554,8 +596,9 @@ class ElasticDiffusion(nn.Module):
             self._undo_coef = torch.stack(rows[:1] + rows).to(dev) if rows else None
         d0, d1 = self.default_size
         self._time_ids.copy_(torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32))  # ED:232-246, 414-418
-        self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
-        self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
+        self._frame_events = {}
+        self._gframes = self._strip_frames(P.gpad, self._timesteps, C, overlap=True)
+        self._vframes = self._strip_frames(P.vpad, self._timesteps, C, overlap=True)
         self._mark("setup_done")
         S.Ks = sorted({R + 1, 1} if S.repaint else {R + 1})
         if getattr(self, "_cn_scale", controlnet_conditioning_scale) != controlnet_conditioning_scale:
