@@ -347,27 +347,33 @@ class ElasticDiffusion(nn.Module):
             chunk = max(1, min(T, (64 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
             plans.append((Hs, Ws, y0, x0, chunk, torch.cat([dr[0] for dr in draws]), torch.cat([dr[1] for dr in draws]),
                           torch.cat([dr[2] for dr in draws])))
-        step = min(p[4] for p in plans)  # timesteps per chunk (strips of one PadPlan come in equal-sized pairs)
+        # timesteps per pass: one VAE-call chunk on a single rank (so that side-stream events are per chunk); the whole
+        # schedule when the encodes are sharded over ranks (each rank then chunks its own share, as in round 1)
+        step = min(p[4] for p in plans) if self.sharder.world_size == 1 else T
         events = []
         with torch.cuda.stream(side):
             coef = coef_host.to(dev)
-            dev_plans = [(Hs, Ws, y0, x0, colour.to(dev), post.to(dev), fwd.to(dev))
-                         for (Hs, Ws, y0, x0, _, colour, post, fwd) in plans]
+            dev_plans = [(Hs, Ws, y0, x0, chunk, colour.to(dev), post.to(dev), fwd.to(dev))
+                         for (Hs, Ws, y0, x0, chunk, colour, post, fwd) in plans]
 
-            def encode_range(Hs, Ws, colour, post, fwd):
+            def encode_range(Hs, Ws, chunk, colour, post, fwd):
                 def encode(ix, *_):
-                    """Noised strips of the timesteps ``ix`` (sharded over ranks like model rows)."""
-                    img = colour[ix][:, :, None, None].expand(ix.numel(), 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
-                    dist = self.vae.encode(img).latent_dist
-                    enc = (dist.mean.float() + dist.std.float() * post[ix]) * sf
-                    cf = coef[ix]
-                    return cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[ix]
+                    """Noised strips of the timesteps ``ix`` (sharded over ranks like model rows), ``chunk`` per VAE call."""
+                    outs = []
+                    for b in range(0, ix.numel(), chunk):
+                        sel = ix[b:b + chunk]
+                        img = colour[sel][:, :, None, None].expand(sel.numel(), 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
+                        dist = self.vae.encode(img).latent_dist
+                        enc = (dist.mean.float() + dist.std.float() * post[sel]) * sf
+                        cf = coef[sel]
+                        outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
+                    return outs[0] if len(outs) == 1 else torch.cat(outs)
                 return encode
 
             for a in range(0, T, step):
                 ix = torch.arange(a, min(T, a + step), device=dev)
-                for (Hs, Ws, y0, x0, colour, post, fwd) in dev_plans:
-                    strips = self.sharder.run(encode_range(Hs, Ws, colour, post, fwd), ix, None, None, None,
+                for (Hs, Ws, y0, x0, chunk, colour, post, fwd) in dev_plans:
+                    strips = self.sharder.run(encode_range(Hs, Ws, chunk, colour, post, fwd), ix, None, None, None,
                                               out_like=((C, Hs, Ws), torch.float32))
                     frames[a:a + ix.numel(), :, y0:y0 + Hs, x0:x0 + Ws] = strips
                 if overlap:
