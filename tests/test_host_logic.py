@@ -274,3 +274,24 @@ def test_miopen_db_derivation_is_idempotent_and_well_formed(tmp_path):
     assert inst in udb[k20.format("NHWC")]
     assert inst in udb[k20.format("NHWC").replace("x320x20x", "x320x32x")]      # borrowed for cfg4's batch 32
     assert tool.CK in udb["2x320x64x64x1x3x3x1x320x20x1x1x0x1x1x0x1x1x0x0x1xNHWCxBF16xF"]  # SD1.5 shape
+
+
+def test_flash_attention_index_math_emulation():
+    """tools/emulate_flash_attention.py: the attention kernel's LDS addresses, MFMA fragment slots and accumulator
+    registers, emulated lane by lane under the documented gfx950 layouts, reproduce softmax(QK^T)V -- ragged Nq / Nk
+    (cross attention's 77 keys) and both V staging paths."""
+    import importlib.util
+    import os
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("emu", os.path.join(root, "tools", "emulate_flash_attention.py"))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    rng = np.random.default_rng(1)
+    Nq, Nk = 70, 77
+    q, k, v = rng.standard_normal((Nq, 64)), rng.standard_normal((Nk, 64)), rng.standard_normal((Nk, 64))
+    want = emu.reference(q, k, v, 0.125)
+    for tr in (True, False):
+        got = emu.run_block(q, k, v, Nq, Nk, 0, 0.125, tr)
+        assert sorted(got) == list(range(Nq))
+        assert max(np.abs(got[r] - want[r]).max() for r in got) < 1e-12
