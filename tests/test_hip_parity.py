@@ -560,3 +560,22 @@ def test_verbose_image_log():
     assert log["global_img"].size == (512, 256)                      # the reduced-resolution generation (32x64 latent)
     assert log["intermediate_x0_imgs"].size == (2 * 1026 + 2, 516)  # 2 logged steps in make_grid's padded layout
     assert set(log["intermediate_cascade_x0_imgs"]) == {"rrg"}
+
+
+@pytest.mark.parametrize("cls_name", ["LinearScheduler", "ConstScheduler"])
+def test_other_rrg_schedulers_vs_oracle(cls_name):
+    """``rrg_scherduler_cls`` other than the cosine default (ED:73-94, 972-979): the product path's own classes and the
+    oracle's give the same latents (rel-L2 < 1e-4) and RNG end state."""
+    import elasticdiffusion_official_amd as pkg
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    kw = dict(height=512, width=768, num_inference_steps=4, guidance_scale=10.0, resampling_steps=2, new_p=0.3,
+              rrg_stop_t=0.4, rrg_init_weight=600, cosine_scale=10.0, repaint_sampling=True)
+    pipe = ElasticDiffusion(DEV, "1.5", view_batch_size=3, unet=FakeUNet(64), vae=FakeVAE(), text_encoder=_embed_fn(False))
+    orc = eo.ElasticOracle(FakeUNet(64), FakeVAE(), DDIMOracle(), _embed_fn(False), sd_version="1.5", view_batch_size=3)
+    pipe.seed_everything(31)
+    z = pipe.generate_latents("p", "", rrg_scherduler_cls=getattr(pkg, cls_name), **kw).cpu()
+    tail = torch.rand(3)
+    orc.seed_everything(31)
+    want = orc.generate_latent("p", "", rrg_scherduler_cls=getattr(eo, cls_name), **kw)
+    assert rel_l2(z, want) < 1e-4, rel_l2(z, want)
+    assert torch.equal(tail, torch.rand(3))

@@ -96,3 +96,44 @@ def test_real_architecture_oracle_leg_is_the_reference(case):
                         **R.LOOP_KW)
     assert torch.equal(cap["z"], want[-1])
     assert torch.equal(torch.rand(4), tail)
+
+
+@pytest.mark.parametrize("cls_name,B", [("LinearScheduler", 1), ("ConstScheduler", 2)])
+def test_other_rrg_schedulers_and_prompt_batches_bit_identical(cls_name, B):
+    """The reference's other RRG weight schedules (ED:73-94, selected through ``rrg_scherduler_cls``, ED:972-979) and a
+    batch of prompts (one latent per prompt, ED:981-1000): oracle == reference bit for bit."""
+    from oracle import elastic_oracle as eo
+    from oracle.ddim import DDIMOracle
+    from tests.fakes import FakeUNet, FakeVAE, synthetic_text_embeds
+    from tests.golden import cases
+    from tests.golden.ref_loader import make_reference_pipeline
+
+    def embeds():
+        (un, pun), (co, pco) = synthetic_text_embeds(B)
+        st = {"n": 0}
+
+        def fn(_):
+            st["n"] += 1
+            return (un, pun) if st["n"] % 2 == 1 else (co, pco)
+        return fn
+
+    kw = dict(cases.E2E_KW, rrg_init_weight=600)
+    prompts = ["p%d" % i for i in range(B)]
+    pipe, ref = make_reference_pipeline(FakeUNet(64), FakeVAE(), DDIMOracle(), embeds(), sd_version="1.5", view_batch_size=3)
+    pipe.random_downasmple_pre = {}
+    cap = {"z": []}
+
+    def grab(z):  # the reference decodes one sample per call (decode_bs = 1, ED:1090, 1121)
+        cap["z"].append(z.clone())
+        return torch.zeros(z.shape[0], 3, 8, 8)
+
+    pipe.decode_latents = grab
+    pipe.seed_everything(31)
+    pipe.generate_image(prompts=prompts, negative_prompts="", height=512, width=768, num_inference_steps=4,
+                        resampling_steps=2, progress=lambda it: it, rrg_scherduler_cls=getattr(ref, cls_name), **kw)
+    tail = torch.rand(3)
+    orc = eo.ElasticOracle(FakeUNet(64), FakeVAE(), DDIMOracle(), embeds(), sd_version="1.5", view_batch_size=3)
+    orc.seed_everything(31)
+    z = orc.generate_latent(prompts, "", height=512, width=768, num_inference_steps=4, resampling_steps=2,
+                            rrg_scherduler_cls=getattr(eo, cls_name), **kw)
+    assert len(cap["z"]) == B and torch.equal(z, torch.cat(cap["z"])) and torch.equal(torch.rand(3), tail)
