@@ -236,6 +236,10 @@ def main():
                     help="images in flight per shard group (generate_latents_interleaved): their pending model calls are "
                          "fused into one forward.  0 = default: max(1, g // 2); 1 = one image at a time.")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative extra measurements after the timed region")
+    ap.add_argument("--all-layouts", action="store_true",
+                    help="N > 2: also measure the one-image-in-flight N-way layout after the timed region (its per-rank "
+                         "batches of 1-5 rows cost MIOpen 30-130 s of one-off warm-up each on first use; at N = 2 the "
+                         "shapes are tuned and it always runs)")
     ap.add_argument("--small", action="store_true",
                     help="REHEARSAL ONLY: reduced-width architecture (models.SMALL_UNET_CONFIGS) so the whole N-rank "
                          "control flow can be exercised in seconds; the metric name says so and the number means nothing")
@@ -362,7 +366,7 @@ def main():
             if world > 1:
                 # the same N GPUs in the other layouts, so that a scaling record cannot pass one off as another
                 alts = []
-                if not (g == world and m == 1):
+                if not (g == world and m == 1) and (world == 2 or args.all_layouts):
                     alts.append(("view_parallel_one_image", world, 1))
                 if world >= 4 and not (g == 2 and m == 1):
                     alts.append(("replica_groups_2way", 2, 1))

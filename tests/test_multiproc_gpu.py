@@ -88,7 +88,7 @@ def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
 
 
 @pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "2", "--in-flight", "2"],
-                                   ["--gpus", "4", "--shard-group", "2", "--in-flight", "2"]])
+                                   ["--gpus", "4", "--shard-group", "2", "--in-flight", "2", "--all-layouts"]])
 def test_bench_multi_rank_rehearsal(flags):
     """bench.py's N > 1 control flow end to end (process groups, row sharding, images in flight, the alternative
     layouts measured after the timed region, max-over-ranks timing, rank 0 printing ONE JSON line) with N ranks sharing
