@@ -38,6 +38,10 @@ WORKLOADS = {
     # configs[3]
     "sdxl_2048x2048_tiled": dict(sd="XL1.0", H=2048, W=2048, vbs=16, R=7, guidance=10.0, new_p=0.3, rrg_w=4000,
                                  cosine_scale=10.0, rrg_stop_t=0.2, tiled=True),
+    # configs[4]: SDXL + ControlNet-depth (elastic_diffusion_w_controlnet.py:1119-1322; conditioning scale of its CLI
+    # example, EDC:1355), condition = a synthetic 512x1024 RGB gradient
+    "sdxl_1024x2048_controlnet": dict(sd="XL1.0", H=1024, W=2048, vbs=16, R=7, guidance=10.0, new_p=0.3, rrg_w=1000,
+                                      cosine_scale=10.0, rrg_stop_t=0.2, tiled=False, controlnet=0.2),
 }
 
 
@@ -48,7 +52,8 @@ def forward_samples(T, R, V, repaint=True):
     return (T - 1) * (per + rep) + per
 
 
-def unet_flops_per_sample(fam, dtype):
+def unet_flops_per_sample(fam, dtype, controlnet=False):
+    """FLOPs of one UNet forward-sample (+ one ControlNet forward when the workload has one), counted on meta tensors."""
     from torch.utils.flop_counter import FlopCounterMode
     from elasticdiffusion_official_amd import models as M
     cfg = M.UNET_CONFIGS[fam]
@@ -60,8 +65,13 @@ def unet_flops_per_sample(fam, dtype):
         kw = None
         if cfg["pooled_projection_dim"]:
             kw = {"text_embeds": torch.empty(1, cfg["pooled_projection_dim"], dtype=dtype), "time_ids": torch.empty(1, 6)}
+        t = torch.empty((), dtype=torch.int64)
         with FlopCounterMode(display=False) as fc:
-            u(x, torch.empty((), dtype=torch.int64), encoder_hidden_states=e, added_cond_kwargs=kw)
+            u(x, t, encoder_hidden_states=e, added_cond_kwargs=kw)
+            if controlnet:
+                c = M.ControlNetModel(cfg).to(dtype)
+                c(x, t, encoder_hidden_states=e, controlnet_cond=torch.empty(1, 3, 8 * S, 8 * S, dtype=dtype),
+                  added_cond_kwargs=kw)
     return float(fc.get_total_flops())
 
 
@@ -245,6 +255,9 @@ def main():
                          "control flow can be exercised in seconds; the metric name says so and the number means nothing")
     ap.add_argument("--cache-backgrounds", action="store_true",
                     help="reuse the noised pad-background frames across images of the same size (off: every image pays)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: initialise RCCL with one rank and send every sharded batch through the all-gather path "
+                         "(what a 1-GPU box can exercise of the multi-GPU exchange)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,13 +285,23 @@ def main():
             groups[size] = made[rank // size]
         return groups[size]
 
-    if world > 1:
+    rccl = None
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         backend = os.environ.get("ED_DIST_BACKEND", "nccl")  # "gloo" only to rehearse the N>1 logic on a 1-GPU box
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        # how many ranks the collective library really connected: an all-reduce of ones over the device tensors (a
+        # SCALE record then shows RCCL saw N ranks, not N independent replicas)
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl = {"backend": dist.get_backend(), "is_rccl": backend == "nccl", "world": dist.get_world_size(),
+                "ranks_seen": int(ones.item()), "device_count_visible": torch.cuda.device_count()}
+        if args.force_exchange:
+            os.environ["ED_FORCE_EXCHANGE"] = "1"
 
     from elasticdiffusion_official_amd import ElasticDiffusion, models, ops
     if os.environ.get("ED_MIOPEN_FIND") == "1":
@@ -292,13 +315,34 @@ def main():
     inject = {}
     if args.small:
         inject["unet"], inject["vae"] = models.build_models(wl["sd"], device=dev, dtype=dtype, small=True)
-    pipe = ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], model_dtype=dtype, process_group=shard_group(g),
-                            cache_backgrounds=args.cache_backgrounds, **inject)
+    cn_scale = wl.get("controlnet")
+    pg = None if (args.force_exchange and world == 1) else shard_group(g)
+    if cn_scale is not None and args.small:
+        inject["unet"], inject["vae"], inject["controlnet"] = models.build_models(wl["sd"], device=dev, dtype=dtype,
+                                                                                  small=True, controlnet=True)
+
+    def make_pipe(group, **inj):
+        """the workload's pipeline class over process group ``group`` (False = unsharded)"""
+        common = dict(view_batch_size=wl["vbs"], model_dtype=dtype, process_group=group,
+                      cache_backgrounds=args.cache_backgrounds, **inj)
+        if cn_scale is not None:
+            from elasticdiffusion_official_amd import ElasticDiffusionControlNet
+            return ElasticDiffusionControlNet(dev, wl["sd"], "depth", **common)
+        return ElasticDiffusion(dev, wl["sd"], **common)
+
+    pipe = make_pipe(pg, **inject)
     kw = dict(height=wl["H"], width=wl["W"], num_inference_steps=args.timesteps, guidance_scale=wl["guidance"],
               resampling_steps=wl["R"], new_p=wl["new_p"], rrg_stop_t=wl["rrg_stop_t"], rrg_init_weight=wl["rrg_w"],
               cosine_scale=wl["cosine_scale"], repaint_sampling=True)
+    cond_img = None
+    if cn_scale is not None:  # synthetic condition at the reduced resolution (EDC:1183-1193): an RGB gradient
+        hh, ww = pipe.get_downsample_size(wl["H"], wl["W"])
+        yy = torch.linspace(0, 1, hh * 8).view(1, 1, -1, 1).expand(1, 1, hh * 8, ww * 8)
+        xx = torch.linspace(0, 1, ww * 8).view(1, 1, 1, -1).expand(1, 1, hh * 8, ww * 8)
+        cond_img = torch.cat([yy, xx, 0.5 * (yy + xx)], dim=1).contiguous()
+        kw.update(condition_image=cond_img, controlnet_conditioning_scale=cn_scale)
     prompt, negative = "An astronaut riding a corgi on the moon", "blurry, ugly, poorly drawn, deformed"
-    state = {"imgs": None}
+    state = {"imgs": None, "latency": None}
 
     def run_images(p, seeds, in_flight):
         """``len(seeds)`` images through pipeline ``p`` (latents + decode); all ranks of p's shard group call this with
@@ -307,14 +351,17 @@ def main():
         if in_flight <= 1:
             for sd_ in seeds:
                 p.seed_everything(sd_)
-                state["imgs"], _ = p.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", **kw)
+                state["imgs"], _ = p.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt",
+                                                    progress=lambda it: it, **kw)
             return
-        jobs = [dict(prompts=prompt, negative_prompts=negative, seed=sd_) for sd_ in seeds]
+        jobs = [dict(prompts=prompt, negative_prompts=negative, seed=sd_, condition_image=cond_img) for sd_ in seeds]
 
         def on_done(j, z):
             state["imgs"] = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])
 
-        p.generate_latents_interleaved(jobs, in_flight=in_flight, on_done=on_done, **kw)
+        kwi = {k: v for k, v in kw.items() if k != "condition_image"}
+        p.generate_latents_interleaved(jobs, in_flight=in_flight, on_done=on_done, **kwi)
+        state["latency"] = p.job_latencies()
 
     def my_seeds(first, count, n_grp, gid):
         """image seeds of this shard group: ``count`` images in total are dealt round-robin to the n_grp groups"""
@@ -347,6 +394,7 @@ def main():
         ops.TIMER.start()
     elapsed = timed(pipe, 0, n_timed, m, n_groups, group_id)
     ktimes = ops.TIMER.stop() if timing else {}
+    lat_timed = state["latency"]
     finite = bool(torch.isfinite(state["imgs"]).all()) if state["imgs"] is not None else True
     phases = pipe.phase_times()
     host_ms = {k: round(1e3 * v, 1) for k, v in pipe.host_s.items()}
@@ -371,9 +419,10 @@ def main():
                 if world >= 4 and not (g == 2 and m == 1):
                     alts.append(("replica_groups_2way", 2, 1))
                 for name, gg, mm in alts:
-                    p2 = pipe if gg == g else ElasticDiffusion(dev, wl["sd"], view_batch_size=wl["vbs"], unet=pipe.unet,
-                                                               vae=pipe.vae, process_group=shard_group(gg),
-                                                               cache_backgrounds=args.cache_backgrounds)
+                    shared = dict(unet=pipe.unet, vae=pipe.vae)
+                    if pipe.controlnet is not None:
+                        shared["controlnet"] = pipe.controlnet
+                    p2 = pipe if gg == g else make_pipe(shard_group(gg), **shared)
                     ng, gid = world // gg, rank // gg
                     cnt = ng * mm
                     run_images(p2, my_seeds(4000, cnt, ng, gid), mm)  # warm (graph capture of this layout's shapes)
@@ -392,7 +441,7 @@ def main():
         V = geometry.ViewPlan(Hl, Wl, vc["window_size"], vc["stride"], vc["context_size"]).V
         T, R = args.timesteps, wl["R"]
         fs = forward_samples(T, R, V)
-        flops_sample = 0.0 if args.small else unet_flops_per_sample(fam, dtype)
+        flops_sample = 0.0 if args.small else unet_flops_per_sample(fam, dtype, controlnet=cn_scale is not None)
         img_per_s = n_timed / elapsed
         sec_per_img = elapsed / n_timed               # wall time per image of the whole job (all N GPUs)
         e2e_tf = fs * flops_sample / sec_per_img / 1e12 / world
@@ -426,11 +475,18 @@ def main():
             mfma = bool(kd["flops_per_image"])
             ach = kd["tflops"] if mfma else kd["gbs"]
             peak = MFMA_BF16_PEAK_TF if mfma else HBM_PEAK_GBS
-            pmc = (load_profile_json("r2_unet_pmc.json") or {}).get("kernels", {}).get(dom)
-            traffic = pmc.get("hbm_bytes_per_launch_mean") if (pmc and args.workload == "sdxl_1024x2048" and T == 50) else None
+            # PMC traffic is measured offline (rocprofv3 --pmc passes, profiles/): one file per workload, newest round first;
+            # a workload without a committed PMC pass reports traffic null rather than another workload's bytes
+            pmc, pmc_file = None, None
+            for fname in (f"r3_unet_pmc_{args.workload}.json", "r3_unet_pmc.json", "r2_unet_pmc.json"):
+                doc = load_profile_json(fname)
+                if doc and doc.get("workload", "sdxl_1024x2048") == args.workload and dom in doc.get("kernels", {}):
+                    pmc, pmc_file = doc["kernels"][dom], fname
+                    break
+            traffic = pmc.get("hbm_bytes_per_launch_mean") if (pmc and T == 50) else None
             roof = {"kernel": dom, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/r2_unet_pmc.json (rocprofv3 --pmc FETCH_SIZE / "
+                    "traffic_source": None if traffic is None else f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / "
                                                                    "WRITE_SIZE passes, offline, mean bytes per launch)",
                     "algorithmic_flops_per_launch": round(kd["flops_per_image"] / kd["launches_per_image"]),
                     "algorithmic_bytes_per_launch": round(kd["bytes_per_image"] / kd["launches_per_image"]),
@@ -455,8 +511,15 @@ def main():
                                        f"{m} image(s) in flight per group; {args.steps} images in total whatever N"),
                        "shard_group": g, "images_in_flight": m,
                        "background_cache": bool(args.cache_backgrounds),
-                       "weights": "random-init SDXL architecture (2.567 B params), seed 0", "vae_dtype": "fp32"},
+                       "controlnet_conditioning_scale": cn_scale,
+                       "weights": f"random-init {fam} architecture" + (" + ControlNet" if cn_scale is not None else "") + ", seed 0",
+                       "vae_dtype": "fp32"},
             "images_per_min": round(60 * img_per_s, 3),
+            "latency_s_per_image": (round(sum(lat_timed) / len(lat_timed), 3) if lat_timed else round(sec_per_img, 3)),
+            "latency_note": (f"{m} image(s) in flight per shard group: the value above is THROUGHPUT (images completed per "
+                             "second); one image takes latency_s_per_image from its first kernel to its decoded pixels"),
+            "rccl": rccl,
+            "tolerance": tolerance_statement(args.dtype),
             "per_view_unet_ms": round(per_view_ms, 3),
             "finite_output": finite,
             "graphs": graph_stats,
@@ -477,25 +540,60 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and not args.small:
             out["cpu_baseline"] = guarded(cpu_baseline, pipe, wl, T, fs, V, args.cpu_baseline)
-            out["parity_bf16_rel_l2"] = guarded(parity_leg, dev)
+            full = load_profile_json("r2_cpu_baseline_full.json")
+            if isinstance(out["cpu_baseline"], dict) and "error" not in out["cpu_baseline"] and full and \
+                    args.workload == "sdxl_1024x2048" and args.cpu_baseline == "bounded":
+                # the bounded sample extrapolates ONE forward-sample; the committed full-mode run (two whole timesteps with
+                # the real fp32 UNet/VAE on the GPU box's host) is the figure to quote
+                out["cpu_baseline"]["full_mode"] = {"value": full.get("value"), "unit": full.get("unit"),
+                                                    "cores": full.get("cores"), "sample": full.get("sample"),
+                                                    "source": "profiles/r2_cpu_baseline_full.json (bench.py --cpu-baseline full)"}
+            out["parity_16bit_rel_l2"] = guarded(parity_leg, dev, args.dtype)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def parity_leg(dev):
+def parity_leg(dev, dtype_name="bf16"):
     """Part of the CPU-baseline leg (the only place bench.py may touch oracle/): the repo's real reduced-width SDXL
-    modules through the product loop in bf16 on the GPU vs the fp32 oracle on the host cores, cfg3 geometry, 2 steps
-    (tests/realarch.py).  -> per-timestep relative L2 of the latent (fp32 product run alongside as the control)."""
+    modules through the product loop in the benchmarked 16-bit dtype on the GPU vs the fp32 oracle on the host cores,
+    cfg3 geometry, 2 steps (tests/realarch.py), next to the reference's own call pattern driving the same 16-bit model
+    and the fp32 product run as the control.  -> per-timestep relative L2 of the latent."""
     from tests import realarch
     t0 = time.perf_counter()
-    rep = realarch.drift_report("cfg3_xl_1024x2048", device=str(dev), with_fp32=True, with_batching=False)
+    rep = realarch.drift_report("cfg3_xl_1024x2048", device=str(dev), with_fp32=True, with_batching=True, dtypes=[dtype_name])
+    ok, msg = realarch.gate_16bit(rep, dtype_name)
+    f = lambda xs: [float(f"{v:.3e}") for v in xs]  # noqa: E731
     return {"case": "reduced-width SDXL architecture (tests/realarch.py), 1024x2048, 2 timesteps, R=2, random init",
-            "bf16_vs_fp32_oracle": [float(f"{v:.3e}") for v in rep["bf16"]],
-            "fp32_vs_fp32_oracle": [float(f"{v:.3e}") for v in rep["fp32"]],
-            "rng_end_state_equal": bool(rep["bf16_rng_tail_equal"] and rep["fp32_rng_tail_equal"]),
+            "dtype": dtype_name,
+            f"{dtype_name}_vs_fp32_oracle": f(rep[dtype_name]),
+            f"reference_call_pattern_{dtype_name}_vs_fp32_oracle": f(rep["ref_pattern_vs_fp32_" + dtype_name]),
+            f"{dtype_name}_vs_reference_call_pattern": f(rep["batching_" + dtype_name]),
+            "fp32_vs_fp32_oracle": f(rep["fp32"]),
+            "gate_1p5x_reference_pattern": {"ok": bool(ok), "detail": msg},
+            "rng_end_state_equal": bool(rep[dtype_name + "_rng_tail_equal"] and rep["fp32_rng_tail_equal"]),
             "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def tolerance_statement(dtype_name):
+    """What the benchmarked dtype meets, with the committed evidence (profiles/r3_precision.json, tools/r3_precision.py):
+    BASELINE.json's 1e-3 rel-L2 is a statement about the fp32 model; a 16-bit UNet -- the reference's own GPU path runs it
+    under fp16 autocast (ED:1012) -- is held to 1.5x the drift of the reference's call pattern with the same 16-bit model."""
+    doc = load_profile_json("r3_precision.json") or {}
+    loop = doc.get("loop", {}).get("cfg3_xl_1024x2048", {})
+    fw = doc.get("full_width", {}).get("batches", {})
+    st = {"fp32_model_vs_reference_cpu_path": {"bar": 1e-3, "measured_max": max(loop["fp32"]) if loop.get("fp32") else None},
+          "benchmarked_dtype": dtype_name,
+          "bar_16bit": "per-timestep rel-L2 vs the fp32 oracle <= 1.5 x that of the reference's call pattern driving the same "
+                       "16-bit model (tests/realarch.gate_16bit; tests/test_real_arch_parity.py)",
+          "evidence": "profiles/r3_precision.json"}
+    if loop.get(dtype_name):
+        st["measured_16bit_vs_fp32_oracle_max"] = max(loop[dtype_name])
+        st["reference_pattern_16bit_vs_fp32_oracle_max"] = max(loop.get("ref_pattern_vs_fp32_" + dtype_name, [float("nan")]))
+    if fw:
+        st["full_width_forward_rel_l2_vs_fp32"] = {b: v.get(dtype_name) for b, v in fw.items()}
+    return st
 
 
 def pick_host_threads():

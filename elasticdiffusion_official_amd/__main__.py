@@ -84,13 +84,25 @@ def main(argv=None):
                                         tiled_decoder=opt.tiled_decoder, **extra)
     torch.cuda.synchronize()
     print(f"Time taken: {time.time() - t0:.2f} seconds")
+    if opt.verbose:  # the reference prints its TimeIt table here (ED:1191-1192); ours: GPU phases + host-side time
+        for name, ms in sd.phase_times().items():
+            print(f"  {name:<14s} {ms / 1e3:9.3f} s (GPU, HIP events)")
+        for name, sec in sd.host_s.items():
+            print(f"  host:{name:<20s} {sec:9.3f} s")
     save_dir = os.path.join(opt.outdir, opt.exp, f"{datetime.now().strftime('%Y-%m-%d %H:%M:%S')}_{opt.seed}")
     os.makedirs(save_dir, exist_ok=True)
     for i, img in enumerate(imgs):
         img.save(f"{save_dir}/{i}.png")
+    for key, logged in image_log.items():  # ED:1201-1205: the verbose image log next to the images
+        if isinstance(logged, dict):
+            for label, img in logged.items():
+                img.save(f"{save_dir}/{key}_{label}.png")
+        else:
+            logged.save(f"{save_dir}/{key}.png")
     with open(f"{save_dir}/args.txt", "w") as f:
         f.write("\n".join(f"{k}: {v}" for k, v in vars(opt).items()))
     print(f"saved {len(imgs)} image(s) to {save_dir}")
+    return save_dir
 
 
 if __name__ == "__main__":

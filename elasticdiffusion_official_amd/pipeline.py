@@ -35,16 +35,21 @@ from .sharding import RowSharder
 # per phase instead of 6-7.  False = the separate entry points (kept for A/B and for the per-kernel parity tests).
 FUSED_GLUE = True
 
-# Experiment switch (default off): compute the pad-strip frames (100 fp32 VAE encodes per SDXL 1024x2048 image, 1.16 s) on
-# a side stream in chunks of timesteps while the denoising loop already runs, the loop waiting stream-side for the chunk
-# that holds the timestep it is about to use.  Measured on the MI355X (gpurun session 12, bench.py --steps 2): 12.73 vs
-# 12.79 s per image -- the UNet already saturates the chip, the VAE kernels only interleave with it -- so the simpler
-# compute-before-the-loop order stays the default.  Single rank only (with row sharding the encodes contain a collective).
-ASYNC_STRIPS = __import__("os").environ.get("ED_ASYNC_STRIPS", "0") == "1"
+# Timesteps per pad-strip VAE call (see _strip_frames: a fixed call shape on every rank count)
+STRIP_CHUNK = 5
 
 
 def _identity_progress(it):
     return it
+
+
+def _default_progress(it):
+    """``progress=tqdm`` is the reference's default (ED:963); the identity when tqdm is not importable."""
+    try:
+        from tqdm import tqdm
+    except ImportError:
+        return it
+    return tqdm(it)
 
 
 def _make_grid(imgs, nrow=8, padding=2):
@@ -102,7 +107,10 @@ class _HostRng:
 
     def __init__(self, seed):
         outer = (torch.get_rng_state(), np.random.get_state())
-        host_rng.seed_everything(seed)
+        # CPU generator + numpy only: ``torch.manual_seed`` would also re-seed every device generator, which this
+        # path never draws from, and the caller's device RNG state is not ours to change
+        torch.default_generator.manual_seed(int(seed))
+        np.random.seed(seed)
         self.state = (torch.get_rng_state(), np.random.get_state())
         torch.set_rng_state(outer[0])
         np.random.set_state(outer[1])
@@ -206,8 +214,6 @@ class ElasticDiffusion(nn.Module):
         # default so that every image pays for its own frames.
         self.cache_backgrounds = cache_backgrounds
         self._frame_cache = {}
-        self._frame_events = {}   # id(frames) -> [(first timestep, event)] of side-stream chunks not yet waited for
-        self._vae_stream = None
         # one hipGraph per model batch shape (graphs.py); falls back to eager launches if a capture fails
         self._runner = GraphedForward(self._forward_rows, enabled=use_graphs)
         self._time_ids = torch.zeros(1, 6, dtype=torch.float32, device=device)  # persistent: captured by the graphs
@@ -313,11 +319,12 @@ class ElasticDiffusion(nn.Module):
         return P
 
     @torch.no_grad()
-    def _strip_frames(self, pad, timesteps, C, overlap=False):
+    def _strip_frames(self, pad, timesteps, C):
         """All noised-background frames [T,C,PH,PW] of one PadPlan (ED:327-391), computed once per image instead of
         2 VAE encodes per global UNet call (the reference's TODO at ED:340).  Contents depend only on
         (dim, side, size, t); the draws come from md5-seeded private generators (host_rng.strip_draws).
-        ``overlap``: enqueue the work on the side stream and register per-chunk events (``_await_frames``)."""
+        (Overlapping these encodes with the loop on a side stream was measured in round 2 -- 12.73 vs 12.79 s per image,
+        the UNet already saturates the chip -- and removed.)"""
         T = len(timesteps)
         if not pad.padded:
             return None
@@ -329,70 +336,42 @@ class ElasticDiffusion(nn.Module):
         sf = self.vae.config.scaling_factor
         s = self.vae_scale_factor
         vae_dtype = next(self.vae.parameters()).dtype
-        overlap = bool(overlap) and ASYNC_STRIPS and self.sharder.world_size == 1
-        main = torch.cuda.current_stream(dev)
-        if overlap:
-            if getattr(self, "_vae_stream", None) is None:
-                self._vae_stream = torch.cuda.Stream(device=dev)
-            side = self._vae_stream
-            side.wait_stream(main)  # the frames buffer (and the previous image's use of the VAE) come first
-        else:
-            side = main
         coef_host = torch.tensor([self.scheduler.add_noise_coefficients(t) for t in timesteps], dtype=torch.float32)
         plans = []
         for (dim, side_id, Hs, Ws, y0, x0) in pad.strips:
             draws = [host_rng.strip_draws(dim, side_id, Hs, Ws, t, C) for t in timesteps]
-            # ~64 MiB of fp32 pixels per VAE call (SDXL: 21 strips); measured 1.17 s per image for the 100 strips vs
-            # 1.77 s with one strip per call
-            chunk = max(1, min(T, (64 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
+            # The unit of work is one VAE call over ``chunk`` consecutive timesteps, and EVERY call has exactly that
+            # batch (the last chunk repeats the final timestep): the convolution shapes MIOpen sees are then the same on
+            # 1, 2, 4 or 8 ranks -- a shape it has not seen costs 30-130 s of one-off kernel builds per process, which
+            # is what round 2's per-rank timestep split (25 -> 21+4 / 13,12 / 7,6 per call) would have paid on the first
+            # real multi-GPU run.  ~16 MiB of fp32 pixels per call, at most STRIP_CHUNK timesteps so that a 50-step
+            # schedule still splits into >= 10 units for 8 ranks.
+            chunk = max(1, min(T, STRIP_CHUNK, (16 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
             plans.append((Hs, Ws, y0, x0, chunk, torch.cat([dr[0] for dr in draws]), torch.cat([dr[1] for dr in draws]),
                           torch.cat([dr[2] for dr in draws])))
-        # timesteps per pass: one VAE-call chunk on a single rank (so that side-stream events are per chunk); the whole
-        # schedule when the encodes are sharded over ranks (each rank then chunks its own share, as in round 1)
-        step = min(p[4] for p in plans) if self.sharder.world_size == 1 else T
-        events = []
-        with torch.cuda.stream(side):
-            coef = coef_host.to(dev)
-            dev_plans = [(Hs, Ws, y0, x0, chunk, colour.to(dev), post.to(dev), fwd.to(dev))
-                         for (Hs, Ws, y0, x0, chunk, colour, post, fwd) in plans]
+        coef = coef_host.to(dev)
+        for (Hs, Ws, y0, x0, chunk, colour, post, fwd) in plans:
+            colour, post, fwd = colour.to(dev), post.to(dev), fwd.to(dev)
+            n_units = -(-T // chunk)
+            # unit u covers timesteps u*chunk .. u*chunk+chunk-1, clamped to T-1 (the repeats are dropped below)
+            sel_all = torch.arange(n_units * chunk, device=dev).clamp_(max=T - 1).view(n_units, chunk)
 
-            def encode_range(Hs, Ws, chunk, colour, post, fwd):
-                def encode(ix, *_):
-                    """Noised strips of the timesteps ``ix`` (sharded over ranks like model rows), ``chunk`` per VAE call."""
-                    outs = []
-                    for b in range(0, ix.numel(), chunk):
-                        sel = ix[b:b + chunk]
-                        img = colour[sel][:, :, None, None].expand(sel.numel(), 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
-                        dist = self.vae.encode(img).latent_dist
-                        enc = (dist.mean.float() + dist.std.float() * post[sel]) * sf
-                        cf = coef[sel]
-                        outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
-                    return outs[0] if len(outs) == 1 else torch.cat(outs)
-                return encode
+            def encode(sel_rows, *_):
+                """Noised strips of the units ``sel_rows`` [n, chunk] (units are sharded over ranks like model rows)."""
+                outs = []
+                for sel in sel_rows:
+                    img = colour[sel][:, :, None, None].expand(chunk, 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
+                    dist = self.vae.encode(img).latent_dist
+                    enc = (dist.mean.float() + dist.std.float() * post[sel]) * sf
+                    cf = coef[sel]
+                    outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
+                return torch.stack(outs)
 
-            for a in range(0, T, step):
-                ix = torch.arange(a, min(T, a + step), device=dev)
-                for (Hs, Ws, y0, x0, chunk, colour, post, fwd) in dev_plans:
-                    strips = self.sharder.run(encode_range(Hs, Ws, chunk, colour, post, fwd), ix, None, None, None,
-                                              out_like=((C, Hs, Ws), torch.float32))
-                    frames[a:a + ix.numel(), :, y0:y0 + Hs, x0:x0 + Ws] = strips
-                if overlap:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    events.append((a, ev))
-        if overlap:
-            self._frame_events[id(frames)] = events
+            strips = self.sharder.run(encode, sel_all, None, None, None, out_like=((chunk, C, Hs, Ws), torch.float32))
+            frames[:, :, y0:y0 + Hs, x0:x0 + Ws] = strips.reshape(n_units * chunk, C, Hs, Ws)[:T]
         if self.cache_backgrounds:
             self._frame_cache[key] = frames
         return frames
-
-    def _await_frames(self, frames, ti):
-        """Make the current stream wait for the side-stream chunk(s) of ``frames`` that cover timestep ``ti``."""
-        evs = self._frame_events.get(id(frames)) if frames is not None else None
-        while evs and evs[0][0] <= ti:
-            torch.cuda.current_stream(self.device).wait_event(evs.pop(0)[1])
-        if evs is not None and not evs:
-            del self._frame_events[id(frames)]
 
     def _embed_rows(self, K, V, un, co, pun, pco):
         """Text rows for one fused model batch: K x [uncond(B), cond(B)] then V x uncond(B)  (ED:436-438, 846-847)."""
@@ -424,7 +403,7 @@ class ElasticDiffusion(nn.Module):
                                 x_rows, text, pooled, cond_rows, t_dev)
 
     # ---- one estimation phase (ED:1016-1035 or ED:1043-1056) ---------------------------------------
-    def _phase_steps(self, P, x, ti, K, g, drop_p, emb, cond=None, direct=True, rrg_w=None, rrg_norm=0.0):
+    def _phase_steps(self, P, x, ti, K, g, drop_p, emb, cond=None, direct=True, rrg_w=None, rrg_norm=0.0, frames=None):
         """Generator: pre-model glue -> ``yield _ModelCall`` (receives the model output rows) -> post-model glue;
         returns (prev, x0, info).  ``direct``: assemble straight into the hipGraph's static input (one image in flight,
         one rank); otherwise into a scratch batch the driver concatenates / the sharder slices.  ``rrg_w``: this is the
@@ -445,10 +424,9 @@ class ElasticDiffusion(nn.Module):
         if P.vpad.strips:
             for _ in range(math.ceil(P.views.V / self.view_batch_size)):
                 host_rng.replay_strip_reseeds(len(P.vpad.strips))
-        self._await_frames(self._gframes, ti)
-        self._await_frames(self._vframes, ti)
-        gframe = None if self._gframes is None else self._gframes[ti]
-        vframe = None if self._vframes is None else self._vframes[ti]
+        gframes, vframes = frames if frames is not None else (self._gframes, self._vframes)
+        gframe = None if gframes is None else gframes[ti]
+        vframe = None if vframes is None else vframes[ti]
         low = torch.empty(K, B, C, P.h, P.w, device=dev, dtype=torch.float32)
         direct = direct and P.one_batch and self.sharder.world_size == 1
         if P.one_batch:
@@ -602,9 +580,8 @@ class ElasticDiffusion(nn.Module):
             self._undo_coef = torch.stack(rows[:1] + rows).to(dev) if rows else None
         d0, d1 = self.default_size
         self._time_ids.copy_(torch.tensor([[d0, d1, 0, 0, d0, d1]], dtype=torch.float32))  # ED:232-246, 414-418
-        self._frame_events = {}
-        self._gframes = self._strip_frames(P.gpad, self._timesteps, C, overlap=True)
-        self._vframes = self._strip_frames(P.vpad, self._timesteps, C, overlap=True)
+        self._gframes = self._strip_frames(P.gpad, self._timesteps, C)
+        self._vframes = self._strip_frames(P.vpad, self._timesteps, C)
         self._mark("setup_done")
         S.Ks = sorted({R + 1, 1} if S.repaint else {R + 1})
         if getattr(self, "_cn_scale", controlnet_conditioning_scale) != controlnet_conditioning_scale:
@@ -615,7 +592,7 @@ class ElasticDiffusion(nn.Module):
         return S
 
     def _program(self, S, prompts, negative_prompts, condition_image=None, trace=None, progress=_identity_progress,
-                 direct=True):
+                 direct=True, frames=None):
         """Generator: the denoising loop of ONE image (ED:981-1078), yielding ``_ModelCall``s; returns the final latent.
         All host RNG draws happen inside, in the reference's order."""
         P = S.P
@@ -643,15 +620,18 @@ class ElasticDiffusion(nn.Module):
             rrg_w = w_i if w_i > 10 else None  # ED:1061-1062
             two_phase = S.repaint and i < S.T - 1
             prev, x0, info = yield from self._phase_steps(P, x, i, S.R + 1, S.guidance, S.drop_p, emb, cond, direct,
-                                                          None if two_phase else rrg_w, S.norm)
+                                                          None if two_phase else rrg_w, S.norm, frames)
+            if logs is not None and logs["init_low"] is None:
+                # ED:1023-1024: taken right after the FIRST direction estimate, i.e. before the RePaint phase replaces
+                # ``info`` with the one of the undone sample (ED:1043)
+                logs["init_low"] = info["init_low"].clone()
             cfg = S.guidance
             if two_phase:  # ED:1038-1056
                 x = self._undo(prev, i + 1)
                 cfg = S.guidance / 3
-                prev, x0, info = yield from self._phase_steps(P, x, i, 1, cfg, S.drop_p, emb, cond, direct, rrg_w, S.norm)
-            if logs is not None:  # verbose image logs (ED:1023-1024, 1058-1059, 1073-1076)
-                if logs["init_low"] is None:
-                    logs["init_low"] = info["init_low"].clone()
+                prev, x0, info = yield from self._phase_steps(P, x, i, 1, cfg, S.drop_p, emb, cond, direct, rrg_w, S.norm,
+                                                              frames)
+            if logs is not None:  # verbose image logs (ED:1058-1059, 1073-1076)
                 if i % self.log_freq == 0:
                     logs["x0"].append(x0.clone())
                     if rrg_w is not None:  # the reduced-resolution x0 the guidance pulls towards (ED:909-921)
@@ -714,15 +694,30 @@ class ElasticDiffusion(nn.Module):
         queue = list(range(len(jobs)))
         live = []  # [job index, program, rng, pending call]
 
+        started = [0]
+
         def start(j):
             job = jobs[j]
             rng = _HostRng(job["seed"])
+            # Every image pays for its own noised pad-background frames, exactly as when it runs alone (they depend only
+            # on geometry and schedule, so the first job takes the ones _setup_run just made and each later job
+            # recomputes identical ones); cache_backgrounds=True is the explicit opt-in to share them (ADVICE r2:
+            # otherwise the N-GPU bench line amortises 100 VAE encodes the 1-GPU line pays per image)
+            frames = None
+            if started[0] and not self.cache_backgrounds:
+                frames = (self._strip_frames(S.P.gpad, self._timesteps, S.C), self._strip_frames(S.P.vpad, self._timesteps, S.C))
+            started[0] += 1
+            with torch.cuda.device(self.device):
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
+            self.job_events[j] = [ev0, None]
             prog = self._program(S, job["prompts"], job.get("negative_prompts", ""), job.get("condition_image"),
-                                 direct=False)
+                                 direct=False, frames=frames)
             with rng:
                 call = next(prog)
             live.append([j, prog, rng, call])
 
+        self.job_events = {}  # job -> [start event, end event] on this device's stream (``job_latencies``)
         while queue and len(live) < max(1, in_flight):
             start(queue.pop(0))
         self.ticks = 0
@@ -756,12 +751,23 @@ class ElasticDiffusion(nn.Module):
                         live.remove(ent)
                         if on_done is not None:
                             on_done(j, stop.value)
+                        with torch.cuda.device(self.device):
+                            ev1 = torch.cuda.Event(enable_timing=True)
+                            ev1.record(torch.cuda.current_stream(self.device))
+                        self.job_events[j][1] = ev1
                         if queue:
                             start(queue.pop(0))
         self.last_latents = results[-1] if results else None
         self.host_s["blocked_ahead_of_gpu"] = self._stager.waited
         self._mark("loop_done")
         return results
+
+    def job_latencies(self):
+        """-> seconds from the start of each job of the last ``generate_latents_interleaved`` call to the end of its
+        ``on_done`` (decode), in job order; synchronises.  With m images in flight the throughput is ~m images per
+        latency: bench.py reports both so a throughput-scaling line cannot be read as a per-image speed-up."""
+        torch.cuda.synchronize(self.device)
+        return [1e-3 * a.elapsed_time(b) for _, (a, b) in sorted(self.job_events.items()) if b is not None]
 
     @_on_own_device
     @torch.no_grad()
@@ -872,7 +878,7 @@ class ElasticDiffusion(nn.Module):
     def generate_image(self, prompts, negative_prompts="", height=768, width=768, num_inference_steps=50,
                        guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
                        rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
-                       progress=_identity_progress, tiled_decoder=False, grid=False, *, condition_image=None,
+                       progress=_default_progress, tiled_decoder=False, grid=False, *, condition_image=None,
                        controlnet_conditioning_scale=1.0, output_type="pil"):
         """ED:953-965 signature (ControlNet keywords of EDC:1120-1134 are keyword-only here).
         Returns ``(images, image_log)``; images are PIL by default, a float tensor with ``output_type='pt'``."""
@@ -939,7 +945,7 @@ class ElasticDiffusionControlNet(ElasticDiffusion):
                        num_inference_steps=50, guidance_scale=10.0, controlnet_conditioning_scale=1.0,
                        resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
                        rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
-                       progress=_identity_progress, tiled_decoder=False, grid=False, *, output_type="pil"):
+                       progress=_default_progress, tiled_decoder=False, grid=False, *, output_type="pil"):
         if condition_image is None:
             raise ValueError("condition_image is required (EDC:1183-1193)")
         h, w = self.get_downsample_size(height, width)

@@ -35,8 +35,16 @@ def row_partition(n_rows, world_size):
     return per, spans
 
 
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3, torch.uint8: 4, torch.int32: 5,
+               torch.int64: 6}
+
+
 class RowSharder:
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force_exchange=None):
+        """``force_exchange``: run the exchange path (pad, all-gather, unpad) even when the group has ONE rank -- how
+        the 1-GPU test box executes RCCL init, the 16-bit ``all_gather_into_tensor`` and its stream ordering against
+        hipGraph replays at all (tests/test_multiproc_gpu.py; env ED_FORCE_EXCHANGE=1 for bench.py)."""
+        import os
         self.group = process_group
         if process_group is False:  # explicit "do not shard" even though torch.distributed is initialised (replicas)
             self.group, self.world_size, self.rank = None, 1, 0
@@ -45,9 +53,32 @@ class RowSharder:
             self.rank = dist.get_rank(process_group)
         else:
             self.world_size, self.rank = 1, 0
+        if force_exchange is None:
+            force_exchange = os.environ.get("ED_FORCE_EXCHANGE") == "1"
+        self.exchange = self.world_size > 1 or (bool(force_exchange) and process_group is not False
+                                                and dist.is_available() and dist.is_initialized())
         self._ix_cache = {}
+        self._validated = set()
         self.rows_computed = 0   # model rows this rank actually ran (bench.py reports it: no duplicated work)
         self.rows_total = 0
+        self.exchanges = 0       # collectives issued (tests assert the exchange path really ran)
+
+    def _validate(self, key, tail, dtype, dev):
+        """Once per batch-shape key: every rank must have arrived at the same output row shape / dtype (a rank that owns
+        no row takes them from ``out_like`` or the input row) -- a disagreement would otherwise be a hang or a corrupted
+        all-gather instead of an error."""
+        if key in self._validated:
+            return
+        desc = [len(tail)] + list(tail) + [0] * (6 - len(tail)) + [_DTYPE_CODE.get(dtype, -1)]
+        gloo = dist.get_backend(self.group) == "gloo"
+        mine = torch.tensor(desc, dtype=torch.int64, device="cpu" if gloo else dev)
+        every = [torch.empty_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(every, mine, group=self.group)
+        for r, other in enumerate(every):
+            if not torch.equal(other.cpu(), mine.cpu()):
+                raise RuntimeError(f"RowSharder: rank {r} expects output rows {other.tolist()} but rank {self.rank} "
+                                   f"{mine.tolist()} for batch {key}: pass out_like= when fn changes the row shape/dtype")
+        self._validated.add(key)
 
     def run(self, fn, x_rows, text=None, pooled=None, cond=None, *more, out_like=None):
         """fn(x, text, pooled, cond, *more) -> out with out.shape[0] == x.shape[0]; returns the full output on every
@@ -56,7 +87,7 @@ class RowSharder:
         (it cannot learn the output shape from a forward it never runs); defaults to the input's row shape / dtype."""
         n = x_rows.shape[0]
         self.rows_total += n
-        if self.world_size == 1:
+        if not self.exchange:
             self.rows_computed += n
             return fn(x_rows, text, pooled, cond, *more)
         per, spans = row_partition(n, self.world_size)
@@ -75,6 +106,7 @@ class RowSharder:
         else:
             tail, dtype = tuple(x_rows.shape[1:]), x_rows.dtype
         dev = x_rows.device
+        self._validate((n, tuple(x_rows.shape[1:]), x_rows.dtype, out_like is not None), tail, dtype, dev)
         if local is not None and local.shape[0] == per:
             send = local
         else:  # short (or empty) share: pad the exchange block, not the compute
@@ -88,6 +120,7 @@ class RowSharder:
             dist.all_gather(parts, send, group=self.group)
         else:
             dist.all_gather_into_tensor(full, send, group=self.group)
+        self.exchanges += 1
         if per * self.world_size == n:
             return full
         key = (n, str(dev))

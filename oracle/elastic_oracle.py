@@ -466,7 +466,7 @@ class ElasticOracle:
                         guidance_scale=10.0, resampling_steps=20, new_p=0.3, rrg_stop_t=0.2, rrg_init_weight=1000,
                         rrg_scherduler_cls=CosineScheduler, cosine_scale=3.0, repaint_sampling=True,
                         progress=lambda it: it, condition_image=None, controlnet_conditioning_scale=1.0,
-                        trace=None):
+                        trace=None, logs=None):
         downsample_size = self.get_downsample_size(height, width)
         self.default_size = (4 * height, 4 * width)
         vc = self.view_config
@@ -495,6 +495,8 @@ class ElasticOracle:
             direction, info = self.approximate_latent_direction_w_resampling(
                 x, t, text_embeds, add_text_embeds, downsample_size, resampling_steps=resampling_steps,
                 drop_p=1 - new_p, **cn)
+            if logs is not None and logs.get("init_downsampled_latent") is None:  # ED:1023-1024
+                logs["init_downsampled_latent"] = info["init_downsampled_latent"]
             local = self.compute_local_uncond_signal(x, t, un, pun, vc, **cn)
             out = self.scheduler.step(local + guidance_scale * direction, t, x)
             x0, nxt, cfg = out["pred_original_sample"], out["prev_sample"], guidance_scale

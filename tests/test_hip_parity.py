@@ -562,6 +562,23 @@ def test_verbose_image_log():
     assert set(log["intermediate_cascade_x0_imgs"]) == {"rrg"}
 
 
+def test_verbose_init_low_matches_oracle():
+    """ED:1023-1024 with RePaint on (the default): the latent the verbose ``global_img`` is generated from is the reduced
+    latent of the FIRST phase (nearest downsample of the initial noise), not the RePaint phase's."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    kw = dict(height=512, width=1024, num_inference_steps=3, guidance_scale=10.0, resampling_steps=2, new_p=0.3,
+              rrg_stop_t=0.4, rrg_init_weight=1000, cosine_scale=10.0, repaint_sampling=True)
+    pipe = ElasticDiffusion(DEV, "1.5", verbose=True, log_freq=2, view_batch_size=4, unet=FakeUNet(64), vae=FakeVAE(),
+                            text_encoder=_embed_fn(False))
+    pipe.seed_everything(23)
+    pipe.generate_latents("p", "", **kw)
+    orc = eo.ElasticOracle(FakeUNet(64), FakeVAE(), DDIMOracle(), _embed_fn(False), sd_version="1.5", view_batch_size=4)
+    orc.seed_everything(23)
+    logs = {}
+    orc.generate_latent("p", "", logs=logs, **kw)
+    assert torch.equal(pipe._logs["init_low"].cpu(), logs["init_downsampled_latent"])
+
+
 @pytest.mark.parametrize("cls_name", ["LinearScheduler", "ConstScheduler"])
 def test_other_rrg_schedulers_vs_oracle(cls_name):
     """``rrg_scherduler_cls`` other than the cosine default (ED:73-94, 972-979): the product path's own classes and the

@@ -117,3 +117,57 @@ def test_bench_multi_rank_rehearsal(flags):
     assert d["graphs"]["eager"] == 0
     if not ("--in-flight" not in flags and g == n):
         assert "view_parallel_one_image" in d["layouts"]
+
+
+def _rccl_worker(port, ret):
+    """One rank, backend "nccl" (= RCCL on ROCm), every forward forced through the exchange path."""
+    import torch.distributed as dist
+    from elasticdiffusion_official_amd import ElasticDiffusion, models
+    from tests import realarch as R
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ones = torch.ones(1, device="cuda:0")
+        dist.all_reduce(ones)
+        c = dict(R.REAL_CASES["cfg3_xl_1024x2048"], steps=2, R=1)
+        xl = True
+        unet, vae, _ = R.build_small(c["sd"])
+        outs = {}
+        for forced in (True, False):
+            pipe = ElasticDiffusion("cuda:0", c["sd"], view_batch_size=c["vbs"], unet=__import__("copy").deepcopy(unet).to(torch.bfloat16),
+                                    vae=__import__("copy").deepcopy(vae), text_encoder=R.embed_fn(xl),
+                                    process_group=None if forced else False)
+            if forced:
+                from elasticdiffusion_official_amd.sharding import RowSharder
+                pipe.sharder = RowSharder(None, force_exchange=True)
+            assert pipe.sharder.exchange == forced and pipe.sharder.world_size == 1
+            pipe.seed_everything(c["seed"])
+            imgs, _ = pipe.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                                          resampling_steps=c["R"], output_type="pt", **R.LOOP_KW)
+            outs[forced] = (pipe.last_latents.cpu().numpy(), pipe.sharder.exchanges, pipe._runner.stats())
+        ret["ranks_seen"] = int(ones.item())
+        ret["backend"] = dist.get_backend()
+        ret["forced"], ret["plain"] = outs[True], outs[False]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_exchange_path():
+    """RCCL itself (backend "nccl") with ONE rank on the test GPU: process-group init, an all-reduce, the bf16
+    ``all_gather_into_tensor`` of every model forward (RowSharder(force_exchange=True)), its stream ordering against the
+    hipGraph replays that produce / consume the exchanged tensors, the fp32 all-gathers of the pad-strip encodes, and
+    ``destroy_process_group`` all execute -- the multi-rank runs on this 1-GPU pool go over gloo, so this is the only
+    place RCCL runs before the driver's 8-GPU box.  The latents must be BIT-identical to the run without the exchange."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    assert ret["backend"] == "nccl" and ret["ranks_seen"] == 1
+    zf, n_exchanges, graphs = ret["forced"]
+    zp, n_plain, _ = ret["plain"]
+    assert n_plain == 0 and n_exchanges >= 3 + 2 * 10  # (2 steps x 2 phases - 1) forwards + 10 strip units x 2 strips
+    assert graphs["eager"] == 0 and graphs["captured"] >= 1
+    np.testing.assert_array_equal(zf, zp)

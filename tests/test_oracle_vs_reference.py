@@ -166,3 +166,37 @@ def test_reference_controlnet_variant_rejects_prompt_batches():
                             controlnet_conditioning_scale=0.2, height=512, width=1024, num_inference_steps=2,
                             resampling_steps=1, progress=lambda it: it, rrg_scherduler_cls=ref.CosineScheduler,
                             **cases.E2E_KW)
+
+
+def test_verbose_init_low_is_the_first_phase_latent():
+    """ED:1023-1024: with verbose=True the reference hands ``generate`` the reduced latent of the FIRST direction
+    estimate (nearest downsample of the initial noise), not the one of the RePaint phase that follows (ED:1043).  The
+    oracle's ``logs['init_downsampled_latent']`` must be that tensor, bit for bit (the product path once took
+    it after the second phase)."""
+    from tests.golden import cases
+    from tests.golden.make_golden import build
+    from tests.test_oracle_golden import make_oracle
+
+    pipe, ref, _ = build("1.5", 64, vbs=4)
+    pipe.verbose, pipe.log_freq = True, 2
+    cap = {}
+
+    class _Stop(Exception):
+        pass
+
+    def grab(latent, *a, **k):  # the reference's first verbose action after the loop (ED:1095)
+        cap["init"] = latent.clone()
+        raise _Stop
+
+    pipe.generate = grab
+    pipe.seed_everything(23)
+    with pytest.raises(_Stop):
+        pipe.generate_image(prompts="p", negative_prompts="", height=512, width=1024, num_inference_steps=3,
+                            resampling_steps=2, progress=lambda it: it, rrg_scherduler_cls=ref.CosineScheduler,
+                            **cases.E2E_KW)
+    orc, _ = make_oracle("1.5", 64, 4)
+    orc.seed_everything(23)
+    logs = {}
+    orc.generate_latent("p", "", height=512, width=1024, num_inference_steps=3, resampling_steps=2, logs=logs,
+                        **cases.E2E_KW)
+    assert torch.equal(logs["init_downsampled_latent"], cap["init"])

@@ -6,12 +6,11 @@ Bars:
   * fp32 model on the GPU vs fp32 oracle: rel-L2 of the latent after every denoising step < 1e-3 (BASELINE.json's
     tolerance; the residual is MIOpen / hipBLASLt vs oneDNN summation order through a real conv/attention stack), and
     the host RNG stream ends in exactly the oracle's state;
-  * bf16 model (fused HIP kernels, flash attention, hipGraph replay): REPORTED per timestep, sanity-bounded at 0.1 --
-    16-bit rounding through a random-init UNet under guidance 10 is a property of the dtype, not of the glue; the
-    reference's own CUDA path runs the UNet under fp16 autocast (ED:1012) and has the same kind of drift against its
-    CPU path;
-  * K-batching: the bf16 product (one fused forward per phase) vs the reference's call pattern driving the same bf16
-    GPU model must sit at the bf16 noise floor: no larger than 2x the bf16-vs-fp32 drift of the reference pattern.
+  * 16-bit models (bf16 and fp16 -- the reference's own CUDA path runs the UNet under fp16 autocast, ED:1012; fused HIP
+    kernels, flash attention, hipGraph replay, K-batched forwards): per-timestep drift vs the fp32 oracle at most 1.5x
+    the drift of the REFERENCE'S call pattern (batch-2 calls per resampling step, view batches) driving the same 16-bit
+    model, and the two 16-bit runs within 2x that of each other (realarch.gate_16bit) -- 16-bit rounding through a
+    random-init UNet under guidance 10 is a property of the dtype; what this repo adds on top of it is what is gated;
 The measured numbers are written to gpurun_out/parity_real_arch.json for DESIGN.md.
 """
 import json
@@ -33,17 +32,41 @@ def reports():
 
 @pytest.mark.parametrize("case", list(R.REAL_CASES))
 def test_real_architecture_in_the_loop(case, reports):
-    rep = R.drift_report(case)
+    rep = R.drift_report(case, dtypes=["bf16", "fp16"])
     reports[case] = rep
     print(json.dumps(rep))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_real_arch.json"), "w") as f:
         json.dump(reports, f, indent=1)
-    assert rep["fp32_rng_tail_equal"] and rep["bf16_rng_tail_equal"]
+    assert rep["fp32_rng_tail_equal"] and rep["bf16_rng_tail_equal"] and rep["fp16_rng_tail_equal"]
     assert max(rep["fp32"]) < 1e-3, rep["fp32"]
-    assert max(rep["bf16"]) < 0.1, rep["bf16"]
     assert rep["graphs"]["eager"] == 0 and rep["graphs"]["captured"] >= 1, rep["graphs"]
-    assert max(rep["batching"]) < 2.0 * max(rep["ref_pattern_vs_fp32"]) + 1e-3, (rep["batching"], rep["ref_pattern_vs_fp32"])
+    for name in ("bf16", "fp16"):  # fp16 = the dtype of the reference's own GPU path (CUDA autocast, ED:1012)
+        ok, msg = R.gate_16bit(rep, name)
+        assert ok, msg
+
+
+def test_16bit_drift_over_many_steps_stays_at_the_reference_patterns():
+    """16 denoising steps at reduced width (SD1.5 architecture, 512x1024): the 16-bit loops must stay finite and within
+    1.5x of the drift the reference's own call pattern shows with the same 16-bit model at EVERY step -- the two-step cases
+    above cannot show a trend."""
+    rep = R.drift_report(R.LONG_CASES["cfg2_sd_512x1024_16steps"], dtypes=["bf16", "fp16"], with_fp32=False)
+    print(json.dumps({k: [float(f"{v:.3e}") for v in rep[k]] for k in rep if isinstance(rep[k], list)}))
+    for name in ("bf16", "fp16"):
+        ok, msg = R.gate_16bit(rep, name)
+        assert ok, msg
+
+
+def test_full_width_sdxl_forward_16bit_error_is_the_dtypes():
+    """ONE forward of the full-width SDXL UNet (2.567 B parameters, batch 6 = the RePaint phase's batch): the fused
+    16-bit path vs fp32 torch ops (MIOpen out of the loop) may err at most 1.5x as much as the plain torch 16-bit path
+    does, for both 16-bit dtypes (every loop-level comparison uses reduced-width modules)."""
+    rep = R.full_width_forward_report("sdxl", batches=(6,))
+    print(json.dumps(rep))
+    for name in ("bf16", "fp16"):
+        r = rep[6][name]
+        assert r["fused_finite"] and r["unfused_finite"], r
+        assert r["fused"] <= 1.5 * r["unfused"] + 1e-4, (name, r)
 
 
 def test_fused_kernels_are_inside_the_bf16_loop():

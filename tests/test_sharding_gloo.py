@@ -121,3 +121,62 @@ def test_sub_groups_shard_independently():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) is True for r in range(world)), dict(ret)
+
+
+def _mismatch_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = RowSharder()
+        x = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(5))  # one row on two ranks: rank 1 owns nothing and must guess the output row shape
+
+        def fn(a, *_):
+            return a.mean(dim=(2, 3))  # changes the row shape: [1,4,8,8] -> [1,4]
+
+        try:
+            sh.run(fn, x)               # no out_like: rank 1 falls back to the input row shape -> mismatch
+            ret[rank] = "no error"
+        except RuntimeError as e:
+            ret[rank] = "raised" if "out_like" in str(e) else f"other: {e}"
+        full = sh.run(fn, x, out_like=((4,), torch.float32))
+        ret[rank + 10] = bool(torch.equal(full, fn(x)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_shape_disagreement_is_an_error_not_a_hang():
+    """A rank that owns no row of a batch takes the output row shape from ``out_like`` (or the input row): if ``fn``
+    changes the shape and the caller forgot ``out_like``, the ranks would all-gather mismatched buffers -- the sharder
+    must detect that (one tiny all-gather per batch shape) and raise on every rank."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0] == "raised" and ret[1] == "raised", dict(ret)
+    assert ret[10] and ret[11]
+
+
+def _forced_worker(port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        x = torch.randn(5, 4, 8, 8)
+        plain, forced = RowSharder(), RowSharder(force_exchange=True)
+        a, b = plain.run(_model, x), forced.run(_model, x)
+        ret["ok"] = bool(torch.equal(a, b)) and plain.exchanges == 0 and forced.exchanges == 1 and not plain.exchange
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_exchange_runs_the_collective_on_one_rank():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and ret["ok"]
