@@ -320,6 +320,472 @@ k_flash_attn_fwd(const Params p) {
   }
 }
 
+
+// =====================================================================================================================
+// Round 3.  Two more kernels behind the same entry point (v_path bits 2 and 3).
+//
+// (1) k_flash_attn_pipe -- the self-attention kernel, software-pipelined inside the wave.  PMC on the round-2 kernel
+//     (profiles/r2_unet_pmc.json) showed the MFMA pipe busy 0.34 of the time: every wave ran QK^T (8 MFMAs), THEN the
+//     whole softmax (~145 VALU / transcendental issues per lane), THEN P V (8 MFMAs), and relied on its two SIMD
+//     neighbours to fill the matrix pipe meanwhile.  Here one loop iteration holds, in ONE basic block,
+//         MFMA :  S(t+1) = K(t+1) Q^T   and   O += V(t-1)^T P(t-1)^T          (16 MFMAs, no dependence on the VALU work)
+//         VALU :  softmax of S(t) -> P(t)                                      (independent of both)
+//     so the in-order wave can issue the softmax instructions into the 32-cycle shadow of each MFMA (up to ~5 issue
+//     slots per MFMA; MI355X_MICROARCH.md "instructions hidden per MFMA gap").  K therefore runs one tile ahead of V:
+//     K double-buffered, V triple-buffered in LDS (55 KiB per workgroup, 2 workgroups per CU at <= 256 VGPRs).
+//     The O rescale of the online softmax is deferred (T13 in the CDNA guide): a row's reference maximum moves only
+//     when the new tile's maximum exceeds it by more than 2^RESCALE_LOG2 (then, and on the first tile, everything at
+//     the old reference -- O and l -- is scaled exactly once; P(t-1) has already been consumed by the MFMAs above).
+//     P stays <= 2^RESCALE_LOG2 in between: harmless for a floating-point P (same relative rounding), fp32 sums.
+//     A ragged last tile (Nk % 64 != 0) is handled after the loop by the un-pipelined masked code.
+//
+// (2) k_flash_attn_smallkv -- cross-attention against the 77 text tokens (Nk <= 96).  The generic kernel pads 77 keys
+//     to two 64-key tiles (40 % of its MFMAs are masked work), runs the online-softmax machinery for a single tile and
+//     re-stages K / V for every 128 query rows.  This kernel is a streaming kernel (the op is HBM-bound: 105 MB of q + out
+//     per 8 GFLOP at batch 20): K and V of one (batch, head) -- three 32-key blocks, zero beyond Nk -- are staged ONCE
+//     per workgroup, which then walks QBLOCKS x 128 query rows: per wave 12 + 12 MFMAs per 32 rows, plain softmax
+//     (no running state, no rescale), keys >= Nk masked.
+// =====================================================================================================================
+constexpr float RESCALE_LOG2 = 6.0f;  // defer the O rescale until a row's maximum grows by more than 2^6 (exp2 domain)
+
+struct SmemPipe {
+  uint16_t k[2][KT * K_LD];
+  uint16_t v[3][KT * V_LD_TR];
+};
+
+template <typename T>
+__device__ __forceinline__ void qk_tile(const uint16_t* kt, int ln, int hi, const typename T::v8 (&qf)[4], f32x16 (&s)[2]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const Vec16 kf = *reinterpret_cast<const Vec16*>(&kt[(32 * kb + ln) * K_LD + 16 * ks + 8 * hi]);
+      s[kb] = T::mfma(as_v8<typename T::v8>(kf), qf[ks], s[kb]);
+    }
+}
+
+// V^T fragment of key step st (16 keys), d block db (32 wide) from a row-major V tile via the LDS transpose read
+__device__ __forceinline__ Vec16 v_frag_tr(const uint16_t* vt, int lane, int hi, int st, int db) {
+  const int row = 16 * st + 4 * hi + ((lane & 15) >> 2);
+  const int col = 32 * db + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&vt[row * V_LD_TR + col]));
+  const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&vt[(row + 8) * V_LD_TR + col]));
+  return __builtin_bit_cast(Vec16, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <typename T>
+__device__ __forceinline__ void pv_tile(const uint16_t* vt, int lane, int hi, const typename T::v8 (&pf)[4], f32x16 (&o)[2]) {
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      o[db] = T::mfma(as_v8<typename T::v8>(v_frag_tr(vt, lane, hi, st, db)), pf[st], o[db]);
+}
+
+// raw buffer access (SRD in SGPRs): 32-bit offsets, out-of-range reads return zeros
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base, int64_t bytes) {
+  // wave-uniform by construction (blockIdx-derived); readfirstlane makes that provable, so no waterfall loops
+  const uint64_t a = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  const uint32_t n = __builtin_amdgcn_readfirstlane((int)(uint32_t)(bytes > 0xffffffffll ? 0xffffffffll : (bytes < 0 ? 0 : bytes)));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), /*stride*/ 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ Vec16 buf_load16(BufRsrc rs, uint32_t voff, uint32_t soff) {
+  const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  Vec16 o = {{v[0], v[1], v[2], v[3]}};
+  return o;
+}
+
+struct True { static constexpr bool value = true; };
+struct False { static constexpr bool value = false; };
+
+// Online-softmax state of one 32-row query block in a wave (per lane: one query row, half of each tile's keys)
+struct SoftmaxRun {
+  float mb;     // reference maximum in the exp2 domain (max * scale * log2 e); deferred, see RESCALE_LOG2
+  float l;      // running sum of the numerators (this lane's half of the keys)
+  float mx;     // scratch: this tile's maximum
+  float use;    // scratch: reference this tile's numerators are taken against
+  float alpha;  // scratch: factor for everything accumulated before this tile (1 = unchanged)
+  float psum;   // scratch
+};
+
+// The softmax of one 64-key tile cut into 16 slices of ~9 VALU / transcendental issues, one per MFMA gap of the
+// pipelined loop (slice i is issued right behind MFMA i).  Flat value index f = 16 kb + r (kb: 32-key block, r: register).
+//   0,1   running maximum of values 16 i .. 16 i + 15 (8 v_max3 each)
+//   2     cross-half maximum, deferred-rescale decision, alpha
+//   3-14  numerators: 3, 3, 2 values per slice (exp2(fma) + sum), and the 16-bit pack of each finished group of 8
+//   15    l = l * alpha + sum
+template <typename T>
+__device__ __forceinline__ void softmax_slice(int i, f32x16 (&s)[2], float sl, SoftmaxRun& r, typename T::v8 (&pf)[4]) {
+  if (i < 2) {
+    float mx = (i == 0) ? -INFINITY : r.mx;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) mx = fmaxf(fmaxf(mx, s[i][j]), s[i][j + 1]);
+    r.mx = mx;
+    asm volatile("" : "+v"(r.mx));
+  } else if (i == 2) {
+    const float mx = fmaxf(r.mx, __shfl_xor(r.mx, 32, 64));  // the two lanes of a query row hold disjoint key halves
+    const float mbn = mx * sl;                                 // sl > 0: scaling commutes with the maximum
+    r.use = (mbn - r.mb > RESCALE_LOG2) ? mbn : r.mb;          // first tile: mb = -inf -> mbn
+    r.alpha = __builtin_amdgcn_exp2f(r.mb - r.use);            // 1 when the reference stays; 0 on the first tile
+    r.mb = r.use;
+    r.psum = 0.f;
+    asm volatile("" : "+v"(r.use), "+v"(r.alpha));
+  } else if (i < 15) {
+    const int g = (i - 3) / 3, w = (i - 3) % 3;        // 4 groups of 8 values: slices of 3, 3, 2
+    const int f0 = 8 * g + 3 * w, n = (w == 2) ? 2 : 3;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      const int f = f0 + j;
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f >> 4][f & 15], sl, -r.use));
+      s[f >> 4][f & 15] = e;
+      r.psum += e;
+    }
+    asm volatile("" : "+v"(r.psum));  // the slice's arithmetic is issued HERE (pure ops would otherwise sink below the fences)
+    if (w == 2) {  // group g complete: B operand of key step g (slot j <-> key 16 g + 8 (j>>2) + 4 hi + (j&3))
+      f32x8 pv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[g >> 1][8 * (g & 1) + j];
+      pf[g] = T::pack(pv);
+      asm volatile("" : "+v"(pf[g]));
+    }
+  } else {
+    r.l = __builtin_fmaf(r.l, r.alpha, r.psum);
+  }
+}
+
+// One loop iteration's compute (see the header comment): 16 MFMAs -- S_next = K(t+1) Q^T, then O += V(t-1)^T P(t-1)^T --
+// each followed by one slice of the softmax of S_cur; the A operand of MFMA i+1 is fetched from LDS before MFMA i is
+// issued.  sched_barrier(0) pins that order (left to itself the scheduler clusters all MFMAs ahead of the softmax).
+template <typename T, bool HAS_PV, bool HAS_NEXT>
+__device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16_t* v_prev, int lane, int ln, int hi,
+                                            const typename T::v8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
+                                            const typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4],
+                                            f32x16 (&o)[2], float sl, SoftmaxRun& run) {
+  constexpr int NQK = HAS_NEXT ? 8 : 0, N = NQK + (HAS_PV ? 8 : 0);
+  auto fetch = [&](int i) -> Vec16 {
+    if (i < NQK) return *reinterpret_cast<const Vec16*>(&k_next[(32 * (i & 1) + ln) * K_LD + 16 * (i >> 1) + 8 * hi]);
+    const int j = i - NQK;
+    return v_frag_tr(v_prev, lane, hi, j >> 1, j & 1);
+  };
+  if (HAS_NEXT) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_next[0][i] = s_next[1][i] = 0.f;
+  }
+  Vec16 a_cur = {{0u, 0u, 0u, 0u}}, a_nxt = {{0u, 0u, 0u, 0u}};
+  if (N > 0) a_cur = fetch(0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < N) {
+      if (i + 1 < N) a_nxt = fetch(i + 1);
+      if (i < NQK) {
+        s_next[i & 1] = T::mfma(as_v8<typename T::v8>(a_cur), qf[i >> 1], s_next[i & 1]);
+        asm volatile("" : "+v"(s_next[i & 1]));
+      } else {
+        const int j = i - NQK;
+        o[j & 1] = T::mfma(as_v8<typename T::v8>(a_cur), p_prev[j >> 1], o[j & 1]);
+        asm volatile("" : "+v"(o[j & 1]));
+      }
+    }
+    softmax_slice<T>(i, s_cur, sl, run, p_cur);
+    if (i + 1 < N) a_cur = a_nxt;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+k_flash_attn_pipe(const Params p) {
+  __shared__ SmemPipe sm;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hi = lane >> 5;
+  int bh, qblk;
+  {
+    const int id = blockIdx.x, per = 8 * p.nqb, grp = id / per, r = id - grp * per;
+    if ((grp + 1) * 8 <= p.BH) {
+      bh = grp * 8 + (r & 7);
+      qblk = r >> 3;
+    } else {
+      bh = grp * 8 + r / p.nqb;
+      qblk = r % p.nqb;
+    }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const uint16_t* qg = p.q + b * p.q_sb + h * D;
+  const uint16_t* kg = p.k + b * p.k_sb + h * D;
+  const uint16_t* vg = p.v + b * p.v_sb + h * D;
+  uint16_t* og = p.o + b * p.o_sb + h * D;
+
+  const int q_row = qblk * QB + wave * 32 + ln;
+  typename T::v8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = as_v8<typename T::v8>(load_row16(qg, p.q_sn, q_row, p.Nq, 16 * ks + 8 * hi));
+
+  // K / V tiles through buffer loads: one wave-uniform descriptor per tensor whose size ends with the last valid row, a
+  // 32-bit per-lane byte offset and a scalar tile offset -- rows past Nk read as zeros (hardware bounds check), no
+  // per-lane 64-bit addresses, no predication branches
+  const BufRsrc k_rs = make_rsrc(kg, ((int64_t)(p.Nk - 1) * p.k_sn + D) * 2);
+  const BufRsrc v_rs = make_rsrc(vg, ((int64_t)(p.Nk - 1) * p.v_sn + D) * 2);
+  const int st_row = tid >> 3, st_col = (tid & 7) * 8;
+  const uint32_t k_off = (uint32_t)(((int64_t)st_row * p.k_sn + st_col) * 2), k_half = (uint32_t)(32 * p.k_sn * 2);
+  const uint32_t v_off = (uint32_t)(((int64_t)st_row * p.v_sn + st_col) * 2), v_half = (uint32_t)(32 * p.v_sn * 2);
+  Vec16 kreg[2], vreg[2];
+  auto load_k = [&](int t) {
+    const uint32_t base = (uint32_t)t * 2u * k_half;
+    kreg[0] = buf_load16(k_rs, k_off, base);
+    kreg[1] = buf_load16(k_rs, k_off, base + k_half);
+  };
+  auto load_v = [&](int t) {
+    const uint32_t base = (uint32_t)t * 2u * v_half;
+    vreg[0] = buf_load16(v_rs, v_off, base);
+    vreg[1] = buf_load16(v_rs, v_off, base + v_half);
+  };
+  auto write_k = [&](int buf) {
+    *reinterpret_cast<Vec16*>(&sm.k[buf][st_row * K_LD + st_col]) = kreg[0];
+    *reinterpret_cast<Vec16*>(&sm.k[buf][(st_row + 32) * K_LD + st_col]) = kreg[1];
+  };
+  auto write_v = [&](int buf) {
+    *reinterpret_cast<Vec16*>(&sm.v[buf][st_row * V_LD_TR + st_col]) = vreg[0];
+    *reinterpret_cast<Vec16*>(&sm.v[buf][(st_row + 32) * V_LD_TR + st_col]) = vreg[1];
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
+  SoftmaxRun run;
+  run.mb = -INFINITY, run.l = 0.f, run.mx = 0.f, run.use = 0.f, run.alpha = 1.f, run.psum = 0.f;
+  const float sl = p.scale_log2e;
+  const int n_tiles = (p.Nk + KT - 1) / KT, n_full = p.Nk / KT;
+
+  load_k(0);
+  load_v(0);
+  write_k(0);
+  write_v(0);
+  if (n_tiles > 1) {
+    load_k(1);
+    write_k(1);
+  }
+  __syncthreads();
+
+  // ping-pong register sets (named, statically indexed: no copies between iterations)
+  f32x16 sA[2], sB[2];
+  typename T::v8 pA[4], pB[4];
+  int vb_prev = 2, vb_cur = 0, vb_next = 1;  // V buffers of tiles t-1, t, t+1 (mod 3)
+
+  // one full (unmasked) tile t: S_cur holds K(t) Q^T on entry
+  auto iter = [&](auto has_pv, auto has_next, int t, f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
+                  typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4]) {
+    load_k(t + 2);  // unconditional: a tile past the end reads as zeros (buffer bounds check) into a buffer nobody reads
+    load_v(t + 1);
+    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value>(sm.k[(t + 1) & 1], sm.v[vb_prev], lane, ln, hi, qf, s_cur,
+                                                                       s_next, p_prev, p_cur, oacc, sl, run);
+    if (__any(run.alpha != 1.0f)) {  // first tile, or a row's maximum grew by more than 2^RESCALE_LOG2 (rare)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        oacc[0][i] *= run.alpha;
+        oacc[1][i] *= run.alpha;
+      }
+    }
+    write_k(t & 1);
+    write_v(vb_next);
+    const int tmp = vb_prev;
+    vb_prev = vb_cur, vb_cur = vb_next, vb_next = tmp;
+    __syncthreads();
+  };
+
+  if (n_full > 0) {
+    qk_tile<T>(sm.k[0], ln, hi, qf, sA);
+    if (n_full == 1) {
+      iter(False{}, False{}, 0, sA, sB, pB, pA);
+    } else {
+      iter(False{}, True{}, 0, sA, sB, pB, pA);
+      int t = 1;  // odd tiles: S in sB, P(t-1) in pA; even tiles: S in sA, P(t-1) in pB
+      for (; t + 2 < n_full; t += 2) {
+        iter(True{}, True{}, t, sB, sA, pA, pB);
+        iter(True{}, True{}, t + 1, sA, sB, pB, pA);
+      }
+      if (n_full - t == 2) {
+        iter(True{}, True{}, t, sB, sA, pA, pB);
+        iter(True{}, False{}, t + 1, sA, sB, pB, pA);
+      } else {
+        iter(True{}, False{}, t, sB, sA, pA, pB);
+      }
+    }
+    // drain: O += V(n_full-1)^T P(n_full-1)^T  (the last tile's V is in vb_prev after the final rotation)
+    if ((n_full - 1) & 1) pv_tile<T>(sm.v[vb_prev], lane, hi, pB, oacc);
+    else pv_tile<T>(sm.v[vb_prev], lane, hi, pA, oacc);
+  }
+
+  if (n_tiles > n_full) {  // ragged last tile: un-pipelined, keys past Nk masked, unconditional rescale
+    f32x16 s[2];
+    qk_tile<T>(sm.k[n_full & 1], ln, hi, qf, s);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (n_full * KT + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float use = fmaxf(run.mb, mx * sl);
+    const float alpha = __builtin_amdgcn_exp2f(run.mb - use);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl, -use));
+        s[kb][r] = e;
+        psum += e;
+      }
+    run.l = __builtin_fmaf(run.l, alpha, psum);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      oacc[0][i] *= alpha;
+      oacc[1][i] *= alpha;
+    }
+    typename T::v8 pf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x8 pv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[st >> 1][8 * (st & 1) + j];
+      pf[st] = T::pack(pv);
+    }
+    pv_tile<T>(sm.v[vb_cur], lane, hi, pf, oacc);
+  }
+
+  const float l_tot = run.l + __shfl_xor(run.l, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_row < p.Nq) {
+    uint16_t* orow = og + (int64_t)q_row * p.o_sn;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x8 tmp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[e] = oacc[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
+        const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
+        Vec8 out8 = {{packed.w[0], packed.w[1]}};
+        *reinterpret_cast<Vec8*>(orow + 32 * db + 8 * g + 4 * hi) = out8;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small-KV (cross-attention) kernel: Nk <= 32 * NKB keys, one pass, K / V staged once per workgroup
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SK_QBLOCKS = 4;  // 128-row query blocks one workgroup walks (K / V staged once for 512 query rows)
+
+template <int NKB>
+struct SmemSmall {
+  uint16_t k[32 * NKB * K_LD];
+  uint16_t v[32 * NKB * V_LD_TR];
+};
+
+template <typename T, int NKB>
+__global__ void __launch_bounds__(256, 2)
+k_flash_attn_smallkv(const Params p) {
+  __shared__ SmemSmall<NKB> sm;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hi = lane >> 5;
+  const int nqg = p.nqb;  // query groups (of SK_QBLOCKS * 128 rows) per (batch, head)
+  const int bh = blockIdx.x / nqg, qgrp = blockIdx.x - bh * nqg;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const uint16_t* qg = p.q + b * p.q_sb + h * D;
+  const uint16_t* kg = p.k + b * p.k_sb + h * D;
+  const uint16_t* vg = p.v + b * p.v_sb + h * D;
+  uint16_t* og = p.o + b * p.o_sb + h * D;
+
+  // stage K and V (rows >= Nk are zeros: their scores are masked, their V rows multiply exact zeros)
+  for (int idx = tid; idx < 32 * NKB * 8; idx += 256) {
+    const int row = idx >> 3, col = (idx & 7) * 8;
+    *reinterpret_cast<Vec16*>(&sm.k[row * K_LD + col]) = load_row16(kg, p.k_sn, row, p.Nk, col);
+    *reinterpret_cast<Vec16*>(&sm.v[row * V_LD_TR + col]) = load_row16(vg, p.v_sn, row, p.Nk, col);
+  }
+  __syncthreads();
+  const float sl = p.scale_log2e;
+
+  for (int qb = 0; qb < SK_QBLOCKS; ++qb) {
+    const int q_row = (qgrp * SK_QBLOCKS + qb) * QB + wave * 32 + ln;
+    if ((qgrp * SK_QBLOCKS + qb) * QB + wave * 32 >= p.Nq) break;  // wave-uniform: nothing left for this wave
+    typename T::v8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = as_v8<typename T::v8>(load_row16(qg, p.q_sn, q_row, p.Nq, 16 * ks + 8 * hi));
+    f32x16 s[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const Vec16 kf = *reinterpret_cast<const Vec16*>(&sm.k[(32 * kb + ln) * K_LD + 16 * ks + 8 * hi]);
+        s[kb] = T::mfma(as_v8<typename T::v8>(kf), qf[ks], s[kb]);
+      }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
+        mx = fmaxf(mx, s[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mb = mx * sl;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl, -mb));
+        s[kb][r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    const float inv = 1.0f / psum;
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2 * NKB; ++st) {
+      f32x8 pv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[st >> 1][8 * (st & 1) + j];
+      const typename T::v8 pf = T::pack(pv);
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        o[db] = T::mfma(as_v8<typename T::v8>(v_frag_tr(sm.v, lane, hi, st, db)), pf, o[db]);
+    }
+    if (q_row < p.Nq) {
+      uint16_t* orow = og + (int64_t)q_row * p.o_sn;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x8 tmp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tmp[e] = o[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
+          const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
+          Vec8 out8 = {{packed.w[0], packed.w[1]}};
+          *reinterpret_cast<Vec8*>(orow + 32 * db + 8 * g + 4 * hi) = out8;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -333,6 +799,31 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   if ((q_sb | q_sn | k_sb | k_sn | v_sb | v_sn) % 8 || (o_sb | o_sn) % 4) return (int)hipErrorInvalidValue;
   Params p;
   p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
+  hipStream_t st = (hipStream_t)stream;
+  if (v_path == 4 || v_path == 8) {  // round-3 kernels: 4 = software-pipelined self-attention, 8 = small-KV (Nk <= 96)
+    if (v_path == 8 && Nk > 96) return (int)hipErrorInvalidValue;
+    // the pipelined kernel addresses K / V with 32-bit byte offsets from the head's base pointer
+    if (v_path == 4 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
+    const int rows_per_wg = v_path == 8 ? QB * SK_QBLOCKS : QB;
+    p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + rows_per_wg - 1) / rows_per_wg;
+    p.q_sb = q_sb, p.q_sn = q_sn, p.k_sb = k_sb, p.k_sn = k_sn, p.v_sb = v_sb, p.v_sn = v_sn, p.o_sb = o_sb, p.o_sn = o_sn;
+    p.scale_log2e = scale * 1.44269504088896340736f;
+    const int64_t nb = (int64_t)p.BH * p.nqb;
+    if (nb > 0x7fffffff) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)nb), block(256);
+    if (dtype != ED_BF16 && dtype != ED_F16) return (int)hipErrorInvalidValue;
+    if (v_path == 4) {
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_pipe<HF><<<grid, block, 0, st>>>(p);
+    } else if (Nk <= 64) {
+      if (dtype == ED_BF16) k_flash_attn_smallkv<BF, 2><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_smallkv<HF, 2><<<grid, block, 0, st>>>(p);
+    } else {
+      if (dtype == ED_BF16) k_flash_attn_smallkv<BF, 3><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_smallkv<HF, 3><<<grid, block, 0, st>>>(p);
+    }
+    return (int)hipGetLastError();
+  }
   // v_path: bit 0 = V staging path (0 transpose-read, 1 V^T tile); bit 1 = 64 query rows per wave (256 per workgroup)
   const int qn = (v_path & 2) ? 2 : 1;
   p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + QB * qn - 1) / (QB * qn);
@@ -341,7 +832,6 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   const int64_t blocks = (int64_t)p.BH * p.nqb;
   if (blocks > 0x7fffffff) return (int)hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(256);
-  hipStream_t st = (hipStream_t)stream;
 #define ED_FA(T)                                                                 \
   if (v_path == 0) k_flash_attn_fwd<T, true, 1><<<grid, block, 0, st>>>(p);      \
   else if (v_path == 1) k_flash_attn_fwd<T, false, 1><<<grid, block, 0, st>>>(p); \

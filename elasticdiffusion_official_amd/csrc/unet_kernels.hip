@@ -18,12 +18,9 @@ namespace {
 // ---- 16-bit element helpers ------------------------------------------------------------------------
 struct BF16 {
   static __device__ __forceinline__ float to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-  static __device__ __forceinline__ uint16_t from_f32(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-  }
+  // gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN) -- one instruction instead of
+  // the six-instruction integer sequence of rounds 1-2
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 };
 struct F16 {
   static __device__ __forceinline__ float to_f32(uint16_t v) { return __half2float(__ushort_as_half(v)); }
@@ -34,6 +31,11 @@ struct alignas(16) U16x8 { uint16_t v[8]; };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// x * rcp(1 + exp2(-x log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~20-instruction expf + IEEE division;
+// the result is rounded to a 16-bit type right after, which absorbs the difference except at rounding ties
+__device__ __forceinline__ float silu_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
 
 // ---- GEGLU: out[m,i] = in[m,i] * gelu(in[m,I+i]) ---------------------------------------------------
 template <typename T>
@@ -314,16 +316,36 @@ k_gn_split_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ ga
 }
 
 // ---- GroupNorm (+SiLU) over channels-last activations [N, HW, C] ------------------------------------
-// Three small launches: (1) per-block partial sums per group, (2) finalise mean / rstd in double, (3) vectorised apply.
-// Reads 2x, writes 1x -- same traffic as the NCHW kernel -- but every access is a full 16-byte channel vector, and the
-// output *is* the transformer's token layout (no permute copy) and the layout MIOpen's CK convolutions consume.
+// Two launches (round 3; three in round 2): (1) per-block partial sums per group, (2) apply, whose blocks first reduce the
+// few KB of partials of their sample themselves (in double, fixed order) instead of waiting for a separate one-block-wide
+// "finalize" launch (17.5 us mean / 113 us max per call in profiles/r2_final_bench_*: 83 ms per image for a few KB).
+// Reads 2x, writes 1x; every access is a full 16-byte channel vector, FOUR rows in flight per thread (the round-2 loops
+// had one load outstanding per thread: 2.7-3.0 TB/s, latency-bound); the output *is* the transformer's token layout
+// (no permute copy) and the layout MIOpen's CK convolutions consume.
 #define GNL_THREADS 256
 
 // Every thread owns a fixed 8-channel column (two when C > 2048) and walks rows, so its sums stay in registers; the
 // reduction over row lanes and then over the columns of each group goes through LDS in a fixed order: no atomics,
-// bit-reproducible statistics.  (The first version re-binned per item with LDS float atomics whenever C/8 did not divide
-// the block size -- every SDXL width -- which was both slow and run-to-run non-deterministic.)
+// bit-reproducible statistics.
 #define GNL_MAXCOL 2  // columns per thread: C <= 8 * 256 * GNL_MAXCOL = 4096
+#define GNL_UNROLL 4  // rows in flight per thread
+
+template <typename T>
+__device__ __forceinline__ void gn_accumulate(const U16x8& v, const U16x8& kbv, bool has_kb, const U16x8& cbv, bool has_cb,
+                                              int split, float& s0, float& q0, float& s1, float& q1) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
+    if (e < split) {
+      s0 += f;
+      q0 += f * f;
+    } else {
+      s1 += f;
+      q1 += f * f;
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ conv_bias,
@@ -348,24 +370,23 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
       if (j >= ncol || vc >= VC) break;
       const int c0 = vc << 3;
       const int split = (c0 / cpg + 1) * cpg - c0;  // channels [0, split) of the vector belong to its first group
-      U16x8 kbv, cbv;
+      U16x8 kbv = {}, cbv = {};
       if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
       if (has_cb) cbv = *reinterpret_cast<const U16x8*>(cbn + c0);
       float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-      for (int row = r0 + my_r; row < r1; row += R) {
-        U16x8 v = *reinterpret_cast<const U16x8*>(base + (int64_t)row * C + c0);
+      const uint16_t* col = base + c0;
+      const int64_t step = (int64_t)R * C;
+      int row = r0 + my_r;
+      for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {  // GNL_UNROLL independent 16-byte loads in flight
+        const uint16_t* p0 = col + (int64_t)row * C;
+        U16x8 v[GNL_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = biased<T>(v.v[e], has_kb ? T::to_f32(kbv.v[e]) : 0.f, has_kb, has_cb ? T::to_f32(cbv.v[e]) : 0.f, has_cb);
-          if (e < split) {
-            s0 += f;
-            q0 += f * f;
-          } else {
-            s1 += f;
-            q1 += f * f;
-          }
-        }
+        for (int u = 0; u < GNL_UNROLL; ++u) v[u] = *reinterpret_cast<const U16x8*>(p0 + u * step);
+#pragma unroll
+        for (int u = 0; u < GNL_UNROLL; ++u) gn_accumulate<T>(v[u], kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
       }
+      for (; row < r1; row += R)
+        gn_accumulate<T>(*reinterpret_cast<const U16x8*>(col + (int64_t)row * C), kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
       float* slot = sh + ((int64_t)my_r * VC + vc) * 4;
       slot[0] = s0, slot[1] = q0, slot[2] = s1, slot[3] = q1;
     }
@@ -389,34 +410,47 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
   }
 }
 
-__global__ void k_gn_nhwc_finalize(const float* __restrict__ partial, float* __restrict__ stats, int G, int nchunks,
-                                   double count, float eps, int NG) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, g)
-  if (t >= NG) return;
-  int n = t / G, g = t % G;
-  double s = 0.0, q = 0.0;
-  for (int c = 0; c < nchunks; ++c) {
-    const float* p = partial + ((int64_t)n * nchunks + c) * 2 * G + 2 * g;
-    s += (double)p[0];
-    q += (double)p[1];
-  }
-  double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[2 * t] = (float)mean;
-  stats[2 * t + 1] = rsqrtf((float)var + eps);
-}
-
-// Same thread <-> column mapping as the statistics kernel: gamma / beta / folded biases / the (at most two) group statistics of
-// a thread's 8 channels are loaded ONCE, then it streams rows: one 16-byte load and one 16-byte store per item, no integer
-// division in the loop.  (The first version was a flat pass with per-item 64-bit div/mod and five side loads per vector:
-// 2.3 TB/s.)
+// Same thread <-> column mapping as the statistics kernel.  Prologue: the block reduces its sample's partial sums
+// [nchunks, G, 2] to mean / rstd per group in LDS -- thread (g, part) adds every GNL_PARTS-th chunk in double, then one
+// thread per group adds the GNL_PARTS parts in ascending order (deterministic) -- then gamma / beta / folded biases / the
+// (at most two) group statistics of a thread's 8 channels are loaded ONCE and it streams rows, GNL_UNROLL at a time.
+#define GNL_MAXG 256
 template <typename T, bool ACT>
 __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
-                const float* __restrict__ stats, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block) {
-  const int n = blockIdx.y, chunk = blockIdx.x;
+                const float* __restrict__ partial, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block,
+                double count, float eps) {
+  __shared__ double red[2 * GNL_THREADS];
+  __shared__ float stats[2 * GNL_MAXG];
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  {
+    const int parts = GNL_THREADS / G > 0 ? GNL_THREADS / G : 1;  // G <= 256
+    const int g = threadIdx.x % G, part = threadIdx.x / G;
+    double s = 0.0, q = 0.0;
+    if (part < parts) {
+      const float* p = partial + (int64_t)n * nchunks * 2 * G + 2 * g;
+      for (int c = part; c < nchunks; c += parts) {
+        s += (double)p[(int64_t)c * 2 * G];
+        q += (double)p[(int64_t)c * 2 * G + 1];
+      }
+    }
+    red[2 * threadIdx.x] = s, red[2 * threadIdx.x + 1] = q;
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+      double ss = 0.0, qq = 0.0;
+      for (int k = 0; k < parts; ++k) {
+        ss += red[2 * (k * G + threadIdx.x)];
+        qq += red[2 * (k * G + threadIdx.x) + 1];
+      }
+      const double mean = ss / count;
+      double var = qq / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stats[2 * threadIdx.x] = (float)mean;
+      stats[2 * threadIdx.x + 1] = rsqrtf((float)var + eps);
+    }
+    __syncthreads();
+  }
   const int VC = C >> 3, cpg = C / G;
   const int ncol = (VC + GNL_THREADS - 1) / GNL_THREADS;
   const int R = ncol == 1 ? GNL_THREADS / VC : 1;
@@ -433,10 +467,10 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
     if (j >= ncol || vc >= VC) break;
     const int c0 = vc << 3;
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;  // C/G >= 8: a vector touches at most two groups
-    const float mean0 = stats[2 * (n * G + g0)], rstd0 = stats[2 * (n * G + g0) + 1];
-    const float mean1 = split < 8 ? stats[2 * (n * G + g0 + 1)] : 0.f, rstd1 = split < 8 ? stats[2 * (n * G + g0 + 1) + 1] : 0.f;
+    const float mean0 = stats[2 * g0], rstd0 = stats[2 * g0 + 1];
+    const float mean1 = split < 8 ? stats[2 * (g0 + 1)] : 0.f, rstd1 = split < 8 ? stats[2 * (g0 + 1) + 1] : 0.f;
     const U16x8 gm = *reinterpret_cast<const U16x8*>(gamma + c0), bt = *reinterpret_cast<const U16x8*>(beta + c0);
-    U16x8 kbv, cbv;
+    U16x8 kbv = {}, cbv = {};
     if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
     if (has_cb) cbv = *reinterpret_cast<const U16x8*>(chan_bias + (int64_t)n * C + c0);
     float a[8], b[8], kb[8], cb[8];
@@ -448,15 +482,28 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
       kb[e] = has_kb ? T::to_f32(kbv.v[e]) : 0.f;
       cb[e] = has_cb ? T::to_f32(cbv.v[e]) : 0.f;
     }
-    for (int row = r0 + my_r; row < r1; row += R) {
-      const int64_t off = (int64_t)row * C + c0;
-      U16x8 v = *reinterpret_cast<const U16x8*>(xb + off), o;
+    auto norm = [&](const U16x8& v) {
+      U16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float y = T::to_f32(T::from_f32(fmaf(a[e], biased<T>(v.v[e], kb[e], has_kb, cb[e], has_cb), b[e])));
-        o.v[e] = ACT ? T::from_f32(silu(y)) : T::from_f32(y);
+        const float y = T::to_f32(T::from_f32(fmaf(a[e], biased<T>(v.v[e], kb[e], has_kb, cb[e], has_cb), b[e])));
+        o.v[e] = ACT ? T::from_f32(silu_fast(y)) : T::from_f32(y);
       }
-      *reinterpret_cast<U16x8*>(ob + off) = o;
+      return o;
+    };
+    const int64_t step = (int64_t)R * C;
+    int row = r0 + my_r;
+    for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {
+      const int64_t off = (int64_t)row * C + c0;
+      U16x8 v[GNL_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GNL_UNROLL; ++u) v[u] = *reinterpret_cast<const U16x8*>(xb + off + u * step);
+#pragma unroll
+      for (int u = 0; u < GNL_UNROLL; ++u) *reinterpret_cast<U16x8*>(ob + off + u * step) = norm(v[u]);
+    }
+    for (; row < r1; row += R) {
+      const int64_t off = (int64_t)row * C + c0;
+      *reinterpret_cast<U16x8*>(ob + off) = norm(*reinterpret_cast<const U16x8*>(xb + off));
     }
   }
 }
@@ -662,6 +709,122 @@ k_bias_residual_add(const uint16_t* __restrict__ h, const uint16_t* __restrict__
   }
 }
 
+// Channels-last form with the GroupNorm kernels' thread <-> column mapping: a thread owns one 8-channel column (its two
+// bias vectors are loaded ONCE, as 16-byte vectors) and streams rows, GNL_UNROLL pairs of 16-byte loads in flight.  The
+// flat kernel above pays a 32-bit modulo and sixteen 2-byte bias loads per vector with one load pair outstanding per
+// thread: 2.7 TB/s on the 263 MB shapes (profiles/r2_final_bench_*).
+template <typename T>
+__global__ void __launch_bounds__(GNL_THREADS)
+k_bias_residual_add_cl(const uint16_t* __restrict__ h, const uint16_t* __restrict__ hb, const uint16_t* __restrict__ res,
+                       const uint16_t* __restrict__ rb, uint16_t* __restrict__ out, int C, int64_t rows, int rows_per_block) {
+  const int VC = C >> 3;
+  const int ncol = (VC + GNL_THREADS - 1) / GNL_THREADS;
+  const int R = ncol == 1 ? GNL_THREADS / VC : 1;
+  const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
+  const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
+  if (ncol == 1 && (int)threadIdx.x >= R * VC) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int j = 0; j < ncol; ++j) {
+    const int vc = my_c + j * GNL_THREADS;
+    if (vc >= VC) break;
+    const int c0 = vc << 3;
+    float b1[8], b2[8];
+    U16x8 hbv = {}, rbv = {};
+    if (hb) hbv = *reinterpret_cast<const U16x8*>(hb + c0);
+    if (rb) rbv = *reinterpret_cast<const U16x8*>(rb + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b1[e] = T::to_f32(hbv.v[e]), b2[e] = T::to_f32(rbv.v[e]);
+    auto add = [&](const U16x8& hv, const U16x8& rv) {
+      U16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = T::to_f32(hv.v[e]), r = T::to_f32(rv.v[e]);
+        if (hb) a = T::to_f32(T::from_f32(a + b1[e]));
+        if (rb) r = T::to_f32(T::from_f32(r + b2[e]));
+        o.v[e] = T::from_f32(r + a);
+      }
+      return o;
+    };
+    const int64_t step = (int64_t)R * C;
+    int64_t row = r0 + my_r;
+    for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {
+      const int64_t off = row * C + c0;
+      U16x8 hv[GNL_UNROLL], rv[GNL_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GNL_UNROLL; ++u) {
+        hv[u] = *reinterpret_cast<const U16x8*>(h + off + u * step);
+        rv[u] = *reinterpret_cast<const U16x8*>(res + off + u * step);
+      }
+#pragma unroll
+      for (int u = 0; u < GNL_UNROLL; ++u) *reinterpret_cast<U16x8*>(out + off + u * step) = add(hv[u], rv[u]);
+    }
+    for (; row < r1; row += R) {
+      const int64_t off = row * C + c0;
+      *reinterpret_cast<U16x8*>(out + off) = add(*reinterpret_cast<const U16x8*>(h + off), *reinterpret_cast<const U16x8*>(res + off));
+    }
+  }
+}
+
+// ---- row softmax, fp32, in place: x[r, :] = softmax(scale * x[r, :]) ---------------------------------------------------
+// The VAE mid-block attention (one head of dim 512 over up to 32768 tokens, fp32 like the rest of the VAE: ED:328 keeps
+// the encoder out of autocast, the decoder runs after it, ED:1080-1121) as  S = Q K^T (fp32 GEMM) -> this kernel -> S V
+// (fp32 GEMM), replacing F.scaled_dot_product_attention, whose ROCm backend is AOTriton's `attn_fwd` -- the last Triton
+// kernel on the path (profiles/r2_final_bench_*: 0.8 % of GPU time).  One 256-thread block per row; the row (<= 128 KiB)
+// is read twice -- online max / sum in one pass, then normalise -- and written once; the second read hits L2.
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_softmax_rows_f32(float* __restrict__ x, int64_t cols, float scale_log2e) {
+  __shared__ float red_m[NT / 64], red_s[NT / 64];
+  float* row = x + (int64_t)blockIdx.x * cols;
+  const int tid = threadIdx.x;
+  float m = -INFINITY, sum = 0.f;
+  const int64_t nv = cols >> 2;
+  for (int64_t i = tid; i < nv; i += NT) {
+    const float4 v = *reinterpret_cast<const float4*>(row + 4 * i);
+    const float a = v.x * scale_log2e, b = v.y * scale_log2e, c = v.z * scale_log2e, d = v.w * scale_log2e;
+    const float mx = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    if (mx > m) {
+      sum *= __builtin_amdgcn_exp2f(m - mx);
+      m = mx;
+    }
+    sum += __builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m) + __builtin_amdgcn_exp2f(d - m);
+  }
+  for (int64_t i = 4 * nv + tid; i < cols; i += NT) {
+    const float a = row[i] * scale_log2e;
+    if (a > m) {
+      sum *= __builtin_amdgcn_exp2f(m - a);
+      m = a;
+    }
+    sum += __builtin_amdgcn_exp2f(a - m);
+  }
+  // wave reduction of (m, sum) pairs, then across the block's waves
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float om = __shfl_xor(m, off, 64), os = __shfl_xor(sum, off, 64);
+    const float nm = fmaxf(m, om);
+    sum = (m == -INFINITY ? 0.f : sum * __builtin_amdgcn_exp2f(m - nm)) + (om == -INFINITY ? 0.f : os * __builtin_amdgcn_exp2f(om - nm));
+    m = nm;
+  }
+  if ((tid & 63) == 0) red_m[tid >> 6] = m, red_s[tid >> 6] = sum;
+  __syncthreads();
+  float gm = red_m[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) gm = fmaxf(gm, red_m[w]);
+  float gs = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) gs += red_m[w] == -INFINITY ? 0.f : red_s[w] * __builtin_amdgcn_exp2f(red_m[w] - gm);
+  const float inv = 1.0f / gs;
+  for (int64_t i = tid; i < nv; i += NT) {
+    float4 v = *reinterpret_cast<const float4*>(row + 4 * i);
+    v.x = __builtin_amdgcn_exp2f(v.x * scale_log2e - gm) * inv;
+    v.y = __builtin_amdgcn_exp2f(v.y * scale_log2e - gm) * inv;
+    v.z = __builtin_amdgcn_exp2f(v.z * scale_log2e - gm) * inv;
+    v.w = __builtin_amdgcn_exp2f(v.w * scale_log2e - gm) * inv;
+    *reinterpret_cast<float4*>(row + 4 * i) = v;
+  }
+  for (int64_t i = 4 * nv + tid; i < cols; i += NT) row[i] = __builtin_amdgcn_exp2f(row[i] * scale_log2e - gm) * inv;
+}
+
 inline int done() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -770,32 +933,22 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
   if (rows_per_block < 1) rows_per_block = 1;
   int nchunks = (HW + rows_per_block - 1) / rows_per_block;
   float* partial = workspace;                                // [N, nchunks, G, 2]
-  float* stats = workspace + (int64_t)N * nchunks * G * 2;   // [N, G, 2]
   dim3 grid1(nchunks, N);
   const int VC_ = C / 8;
   size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= GNL_THREADS ? GNL_THREADS / VC_ : 1);
-  int NG = N * G;
 #define GNL_RUN(T)                                                                                                     \
   k_gn_nhwc_partial<T><<<grid1, GNL_THREADS, lds, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                \
                                                        (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
-  k_gn_nhwc_finalize<<<(NG + 127) / 128, 128, 0, s>>>(partial, stats, G, nchunks, (double)HW * (C / G), eps, NG);      \
   if (act_silu)                                                                                                        \
     k_gn_nhwc_apply<T, true><<<grid1, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
                                                           (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
-                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, \
-                                                          rows_per_block);                                             \
+                                                          (const uint16_t*)chan_bias, partial, (uint16_t*)out, C, HW,  \
+                                                          G, rows_per_block, (double)HW * (C / G), eps);               \
   else                                                                                                                 \
     k_gn_nhwc_apply<T, false><<<grid1, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                \
                                                            (const uint16_t*)beta, (const uint16_t*)conv_bias,          \
-                                                           (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW, G, \
-                                                           rows_per_block);
-  if (dtype == ED_BF16) {
-    GNL_RUN(BF16)
-  } else if (dtype == ED_F16) {
-    GNL_RUN(F16)
-  } else {
-    return (int)hipErrorInvalidValue;
-  }
+                                                           (const uint16_t*)chan_bias, partial, (uint16_t*)out, C, HW, \
+                                                           G, rows_per_block, (double)HW * (C / G), eps);
 #undef GNL_RUN
   return done();
 }
@@ -851,6 +1004,21 @@ int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, con
   if (total_vec >= 0x7fffffff) return (int)hipErrorInvalidValue;
   int grid = (int)((total_vec + 255) / 256 < 16384 ? (total_vec + 255) / 256 : 16384);
   hipStream_t s = (hipStream_t)stream;
+  if (channels_last && C <= 8 * GNL_THREADS * GNL_MAXCOL && (dtype == ED_BF16 || dtype == ED_F16) &&
+      !(((uintptr_t)h_bias | (uintptr_t)res_bias) & 15u)) {
+    const int64_t rows = (int64_t)N * HW;
+    int rows_per_block = (65536 + C - 1) / C;  // ~64 K elements per block, as the GroupNorm kernels
+    const int64_t nblk = (rows + rows_per_block - 1) / rows_per_block;
+    if (nblk <= 0x7fffffff) {
+      if (dtype == ED_BF16)
+        k_bias_residual_add_cl<BF16><<<(unsigned)nblk, GNL_THREADS, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
+                                                                         (const uint16_t*)res_bias, (uint16_t*)out, C, rows, rows_per_block);
+      else
+        k_bias_residual_add_cl<F16><<<(unsigned)nblk, GNL_THREADS, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
+                                                                        (const uint16_t*)res_bias, (uint16_t*)out, C, rows, rows_per_block);
+      return done();
+    }
+  }
   if (dtype == ED_BF16)
     k_bias_residual_add<BF16><<<grid, 256, 0, s>>>((const uint16_t*)h, (const uint16_t*)h_bias, (const uint16_t*)res,
                                                    (const uint16_t*)res_bias, (uint16_t*)out, C, HW, total_vec,
@@ -877,6 +1045,14 @@ int ed_tokens_add_nchw(const void* x, const void* tokens, void* out, int dtype, 
     k_tokens_add_nchw<F16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)tokens, (uint16_t*)out, C, HW);
   else
     return (int)hipErrorInvalidValue;
+  return done();
+}
+
+int ed_softmax_rows(void* x, int64_t rows, int64_t cols, float scale, void* stream) {
+  if (rows == 0 || cols == 0) return 0;
+  if (rows < 0 || cols < 0 || rows > 0x7fffffffll || ((uintptr_t)x & 15u) || (cols % 4 != 0 && rows > 1))
+    return (int)hipErrorInvalidValue;  // rows start 16-byte aligned when cols % 4 == 0
+  k_softmax_rows_f32<256><<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>((float*)x, cols, scale * 1.44269504088896340736f);
   return done();
 }
 

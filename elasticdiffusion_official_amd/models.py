@@ -84,6 +84,7 @@ FUSED_ADD_LAYERNORM = True  # BasicTransformerBlock: residual add + next LayerNo
 FUSED_TOKENS_ADD = True     # Transformer2DModel: tokens -> NCHW + residual in one kernel (ed_tokens_add_nchw)
 FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit) instead of SDPA / AOTriton
 FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
+VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_rows + fp32 GEMM instead of SDPA (AOTriton)
 # A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
 for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
     if _name not in globals() or not isinstance(globals()[_name], bool):
@@ -588,8 +589,13 @@ class _VaeAttention(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         h = self.group_norm(x).view(B, C, H * W).transpose(1, 2)
-        q, k, v = (f(h).unsqueeze(1) for f in (self.to_q, self.to_k, self.to_v))
-        o = F.scaled_dot_product_attention(q, k, v).squeeze(1)
+        if VAE_HIP_ATTENTION and h.is_cuda and h.dtype == torch.float32 and (H * W) % 4 == 0:
+            # two fp32 library GEMMs around ed_softmax_rows: no AOTriton (Triton) kernel on the path
+            from . import ops
+            o = ops.vae_attention(self.to_q(h), self.to_k(h), self.to_v(h))
+        else:
+            q, k, v = (f(h).unsqueeze(1) for f in (self.to_q, self.to_k, self.to_v))
+            o = F.scaled_dot_product_attention(q, k, v).squeeze(1)
         return self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W) + x
 
 

@@ -425,17 +425,59 @@ def tokens_add_nchw(x, tokens):
     return out
 
 
+def softmax_rows_(x, scale=1.0):
+    """x fp32 [..., cols] contiguous -> softmax(scale * x) over the last dim, IN PLACE (ed_softmax_rows)."""
+    cols = x.shape[-1]
+    if cols % 4 and x.numel() != cols:
+        _reject("softmax_rows_: cols must be a multiple of 4")
+    TIMER.note_work("ed_softmax_rows", nbytes=3.0 * x.numel() * 4)
+    _call("ed_softmax_rows", _dev(x, torch.float32, "x"), x.numel() // cols, cols, float(scale), _stream())
+    return x
+
+
+VAE_ATTENTION_CHUNK_BYTES = 4 << 30  # score-matrix bytes materialised at a time by vae_attention
+
+
+def vae_attention(q, k, v):
+    """softmax(q k^T / sqrt(C)) v for the VAE's single-head attention, fp32 [B, N, C]: two library fp32 GEMMs around
+    ed_softmax_rows, over chunks of query rows so that the [rows, N] score block stays under VAE_ATTENTION_CHUNK_BYTES
+    (N = 32768 tokens for the 1024x2048 decode: 4.3 GB of scores per sample).  Replaces SDPA / AOTriton."""
+    B, N, C = q.shape
+    scale = C ** -0.5
+    rows = max(256, min(N, VAE_ATTENTION_CHUNK_BYTES // (4 * N * B) // 256 * 256)) if N > 256 else N
+    kt = k.transpose(1, 2)
+    if rows >= N:
+        return torch.bmm(softmax_rows_(torch.bmm(q, kt), scale), v)
+    out = torch.empty_like(q)
+    for a in range(0, N, rows):
+        s = torch.bmm(q[:, a:a + rows], kt)                      # [B, rows, N]
+        out[:, a:a + rows] = torch.bmm(softmax_rows_(s, scale), v)
+    return out
+
+
 # kernel variant (identical results): bit 0 = V staging (0: ds_read_b64_tr_b16 from a row-major V tile, 1: V^T tile in
 # LDS); bit 1 = 64 query rows per wave (256 per workgroup) instead of 32.  None = choose per shape: the 64-row variant is
 # faster only when there is enough work to fill the chip with half as many workgroups (measured, batch 20: N=4096
 # 848 vs 776 TFLOP/s; N=1024 and the 77-key cross attention: no gain or slower; profiles/r2_s7_probe_attn.jsonl)
+# Round 3: 4 = software-pipelined self-attention kernel, 8 = small-KV kernel (Nk <= 96: the 77-token cross attention).
 FLASH_V_PATH = None
+_ENV_VARIANT = __import__("os").environ.get("ED_FLASH_VARIANT")  # A/B: "legacy" = the round-2 choice, or a variant number
 
 
-def _flash_variant(B, heads, Nq, Nk):
+def _flash_variant(B, heads, Nq, Nk, k=None, v=None):
     if FLASH_V_PATH is not None:
         return int(FLASH_V_PATH)
-    return 2 if (Nq >= 2048 and Nk >= 1024 and B * heads * (Nq // 256) >= 1024) else 0
+    legacy = 2 if (Nq >= 2048 and Nk >= 1024 and B * heads * (Nq // 256) >= 1024) else 0
+    if _ENV_VARIANT == "legacy":
+        return legacy
+    if _ENV_VARIANT is not None:
+        want = int(_ENV_VARIANT)
+        return want if (want != 8 or Nk <= 96) else legacy
+    if Nk <= 96:
+        return 8
+    if Nk >= 128 and (k is None or (Nk + 128) * max(k.stride(1), v.stride(1)) * 2 < 2 ** 31):
+        return 4
+    return legacy
 
 
 def flash_attention(q, k, v, heads, v_path=None):
@@ -459,5 +501,5 @@ def flash_attention(q, k, v, heads, v_path=None):
                     nbytes=2.0 * q.element_size() * HD * B * (Nq + Nk))
     _call("ed_flash_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _code(q, "q"), B, heads, Nq, Nk,
           64, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
-          0.125, _flash_variant(B, heads, Nq, Nk) if v_path is None else int(v_path), _stream())
+          0.125, _flash_variant(B, heads, Nq, Nk, k, v) if v_path is None else int(v_path), _stream())
     return out

@@ -290,11 +290,23 @@ int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const flo
  *   out dtype [B, Nq, H, 64]   strides o_sb, o_sn
  *   head_dim must be 64; dtype = ED_F16 | ED_BF16; q/k/v 16-byte aligned with strides % 8 == 0, out 8-byte aligned
  *   with strides % 4 == 0.  Nk need not be a multiple of the 64-key tile (cross-attention: 77 text tokens).
- *   v_path: 0 = V transposed on the fly by ds_read_b64_tr_b16, 1 = V^T tile staged in LDS (same result).
+ *   v_path: kernel variant.  0 = V transposed on the fly by ds_read_b64_tr_b16, 1 = V^T tile staged in LDS; +2 = 64
+ *   query rows per wave (0..3 give bit-identical results).  4 = software-pipelined kernel (softmax of tile t issued in
+ *   the shadow of the MFMAs of tiles t+1 / t-1, deferred O rescale; K / V addressed with 32-bit offsets: returns
+ *   hipErrorInvalidValue when (Nk + 128) * max(k_sn, v_sn) * 2 >= 2^31).  8 = small-KV kernel for Nk <= 96 (cross
+ *   attention on the 77 text tokens: K / V staged once per 512 query rows, single pass, no online rescale).
+ *   4 and 8 agree with 0..3 to the rounding of P (same fp32 accumulation, different summation grouping).
  */
 int ed_flash_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,
                        int head_dim, int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,
                        int64_t o_sb, int64_t o_sn, float scale, int v_path, void* stream);
+
+/*
+ * ed_softmax_rows -- x[r, :] = softmax(scale * x[r, :]) in place, fp32, rows x cols contiguous (cols % 4 == 0).  The VAE
+ * mid-block attention (AutoencoderKL inside ED:270 decode / ED:350 encode; one 512-wide head, fp32) runs as
+ * Q K^T (library fp32 GEMM) -> ed_softmax_rows -> S V (library fp32 GEMM) instead of the AOTriton SDPA kernel.
+ */
+int ed_softmax_rows(void* x, int64_t rows, int64_t cols, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,3 +39,19 @@ def test_bench_and_cli_help_run_without_gpu():
     for cmd in ([sys.executable, "bench.py", "--help"], [sys.executable, "-m", "elasticdiffusion_official_amd", "--help"]):
         out = subprocess.run(cmd, capture_output=True, text=True, cwd=bench.ROOT)
         assert out.returncode == 0 and "--" in out.stdout, out.stderr
+
+
+def test_workloads_cover_every_baseline_config_and_controlnet_flops():
+    import torch
+    assert set(bench.WORKLOADS) == {"sdxl_1024x2048", "sd15_512x1024", "sdxl_2048x2048_tiled", "sdxl_1024x2048_controlnet"}
+    cn = bench.WORKLOADS["sdxl_1024x2048_controlnet"]
+    assert cn["controlnet"] == 0.2 and (cn["H"], cn["W"], cn["R"]) == (1024, 2048, 7)   # EDC:1355, cfg5 = cfg3 + ControlNet
+    base = bench.unet_flops_per_sample("sdxl", torch.bfloat16)
+    with_cn = bench.unet_flops_per_sample("sdxl", torch.bfloat16, controlnet=True)
+    assert 1.2 * base < with_cn < 1.6 * base   # the ControlNet is the UNet's encoder half + zero convs
+
+
+def test_tolerance_statement_shape():
+    st = bench.tolerance_statement("bf16")
+    assert st["fp32_model_vs_reference_cpu_path"]["bar"] == 1e-3 and st["benchmarked_dtype"] == "bf16"
+    assert "1.5 x" in st["bar_16bit"] and st["evidence"] == "profiles/r3_precision.json"

@@ -195,13 +195,15 @@ def _attn_ref(q, k, v, H):
     return (torch.softmax(s, dim=-1) @ vf).transpose(1, 2).reshape(B, Nq, HD)
 
 
-@pytest.mark.parametrize("v_path", [0, 1, 2, 3])  # bit 0: V staging path; bit 1: 64 query rows per wave
+@pytest.mark.parametrize("v_path", [0, 1, 2, 3, 4, 8])  # bit 0: V staging; bit 1: 64 rows per wave; 4: pipelined; 8: small-KV
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 10, 4096, 4096), (3, 20, 1024, 1024), (2, 20, 1024, 77), (1, 10, 4096, 77),
                                        (2, 2, 256, 256), (1, 4, 64, 64), (1, 1, 100, 77), (2, 3, 200, 333), (1, 2, 1, 1)])
 def test_flash_attention(dtype, B, H, Nq, Nk, v_path):
     """ed_flash_attention vs the fp32 reference; it must be as accurate as the library kernel it replaces (SDPA)."""
     from elasticdiffusion_official_amd import ops
+    if v_path == 8 and Nk > 96:
+        pytest.skip("the small-KV kernel takes Nk <= 96")
     g = torch.Generator(device=DEV).manual_seed(Nq * 7 + Nk)
     q, k, v = (torch.randn(B, n, H * 64, device=DEV, generator=g).mul(s).to(dtype) for n, s in ((Nq, 1.5), (Nk, 1.5), (Nk, 1.0)))
     got = ops.flash_attention(q, k, v, H, v_path=v_path)
@@ -234,9 +236,41 @@ def test_flash_attention_strided_inputs_and_outlier_rows():
     assert float((got.float() - ref).abs().max()) < 3e-2
     assert float((got[0, 5, :64].float() - v[0, 600, :64].float()).abs().max()) < 3e-2   # ~one-hot row
     assert float((got[1, 7].float() - v[1].float().mean(0)).abs().max()) < 2e-2          # ~mean of V
+    base = ops.flash_attention(q, k, v, H, v_path=0)
     for path in (0, 1, 2, 3):
         again = ops.flash_attention(q.contiguous(), k.contiguous(), v.contiguous(), H, v_path=path)
-        assert torch.equal(again, got)  # strides, the V staging path and the rows-per-wave variant do not change a bit
+        assert torch.equal(again, base)  # strides, the V staging path and the rows-per-wave variant do not change a bit
+    # the pipelined kernel (deferred rescale: the outlier row takes the rescale branch in a late tile) on strided and on
+    # contiguous inputs: identical to itself, and within the rounding of P of the others
+    piped = ops.flash_attention(q, k, v, H, v_path=4)
+    assert torch.equal(piped, ops.flash_attention(q.contiguous(), k.contiguous(), v.contiguous(), H, v_path=4))
+    assert float((piped.float() - ref).abs().max()) < 3e-2
+    assert float((piped[0, 5, :64].float() - v[0, 600, :64].float()).abs().max()) < 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_flash_attention_deferred_rescale_branches(dtype):
+    """The pipelined kernel moves a row's reference maximum only when a tile's maximum exceeds it by more than 2^6 (exp2
+    domain): force (a) rows whose maximum creeps up by less than the threshold every tile (never rescaled after the first
+    tile: P grows up to 2^6), (b) rows that jump far above it in a late tile, (c) rows whose first tile is the largest --
+    against the fp32 reference on the full tensor (CDNA guide 5.4 rule 26: a rare data-dependent branch needs its own test)."""
+    from elasticdiffusion_official_amd import ops
+    B, H, N = 1, 2, 1024
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q = torch.randn(B, N, H * 64, device=DEV, generator=g).to(dtype)
+    k = (0.3 * torch.randn(B, N, H * 64, device=DEV, generator=g)).to(dtype)
+    v = torch.randn(B, N, H * 64, device=DEV, generator=g).to(dtype)
+    qh = q.view(B, N, H, 64)
+    kh = k.view(B, N, H, 64)
+    for tile in range(1, 16):      # (a) head 0, query 3: score of key 64*tile grows by ~2.9 (4.2 in log2 units) per tile
+        kh[0, 64 * tile, 0] = (qh[0, 3, 0].float() * (0.35 * tile * 8.0 / float(qh[0, 3, 0].float().pow(2).sum()))).to(dtype)
+    kh[0, 900, 1] = (qh[0, 9, 1].float().sign() * 6.0).to(dtype)   # (b) head 1, query 9: a huge score in tile 14
+    kh[0, 5, 1] = (qh[0, 17, 1].float().sign() * 6.0).to(dtype)     # (c) head 1, query 17: the largest score in tile 0
+    ref = _attn_ref(q, k, v, H)
+    for path in (4, 0):
+        got = ops.flash_attention(q, k, v, H, v_path=path)
+        err = float((got.float() - ref).abs().max())
+        assert err < (2e-2 if dtype == torch.bfloat16 else 4e-3), (path, err)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -355,3 +389,34 @@ def test_unet_round2_fusions_close():
     ra, rb = float((a - ref).norm() / ref.norm()), float((b - ref).norm() / ref.norm())
     print(f"small SDXL UNet bf16 vs fp32: fused {ra:.3e}, unfused {rb:.3e}")
     assert ra < 1.5 * rb + 1e-3, (ra, rb)
+
+
+@pytest.mark.parametrize("rows,cols,scale", [(7, 4096, 0.0442), (3, 32768, 0.0442), (64, 256, 1.0), (1, 4, 2.0), (5, 1028, 0.3)])
+def test_softmax_rows(rows, cols, scale):
+    from elasticdiffusion_official_amd import ops
+    x = torch.randn(rows, cols, device=DEV) * 3.0
+    x[0, 3] = 40.0  # a dominant entry
+    want = torch.softmax(x.double() * scale, dim=-1)
+    got = ops.softmax_rows_(x.clone(), scale)
+    assert float((got.double() - want).abs().max()) < 2e-6
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 1024, 512), (1, 4096, 64), (3, 260, 32)])
+def test_vae_attention_matches_sdpa_math(B, N, C):
+    """ops.vae_attention (fp32 GEMM -> ed_softmax_rows -> fp32 GEMM, chunked over query rows) vs the fp64 formula, and as
+    close to it as torch's own SDPA on the same fp32 inputs."""
+    from elasticdiffusion_official_amd import ops
+    q, k, v = (torch.randn(B, N, C, device=DEV) for _ in range(3))
+    ref = torch.softmax(q.double() @ k.double().transpose(1, 2) * C ** -0.5, dim=-1) @ v.double()
+    saved = ops.VAE_ATTENTION_CHUNK_BYTES
+    try:
+        for chunk in (saved, 4 * N * B * 300):  # one block of rows, and several ragged ones
+            ops.VAE_ATTENTION_CHUNK_BYTES = chunk
+            got = ops.vae_attention(q, k, v)
+            err = float((got.double() - ref).abs().max())
+            sdpa = F.scaled_dot_product_attention(q.unsqueeze(1), k.unsqueeze(1), v.unsqueeze(1)).squeeze(1)
+            err_sdpa = float((sdpa.double() - ref).abs().max())
+            assert err < max(2 * err_sdpa, 2e-5), (err, err_sdpa)
+    finally:
+        ops.VAE_ATTENTION_CHUNK_BYTES = saved
