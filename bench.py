@@ -237,7 +237,9 @@ def main():
                     help="bounded: ~10-30 s sample (default); full: SURVEY 8(d)'s cfg1 in full + two full timesteps of "
                          "the workload (minutes of host time; run once, result kept under profiles/)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"],
+                    help="UNet / ControlNet dtype.  fp16 (default) is the reference's own GPU dtype (autocast, ED:1012) and "
+                         "drifts 8x less than bf16 against the fp32 reference path (profiles/r3_precision.json)")
     ap.add_argument("--shard-group", type=int, default=0,
                     help="GPUs that row-shard the SAME images (RCCL all-gather per forward).  0 = all N (default): every "
                          "rank works on every image -- view/row-parallel strong scaling.  g < N: N/g independent groups "

@@ -949,6 +949,13 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
                                                            (const uint16_t*)beta, (const uint16_t*)conv_bias,          \
                                                            (const uint16_t*)chan_bias, partial, (uint16_t*)out, C, HW, \
                                                            G, rows_per_block, (double)HW * (C / G), eps);
+  if (dtype == ED_BF16) {
+    GNL_RUN(BF16)
+  } else if (dtype == ED_F16) {
+    GNL_RUN(F16)
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
 #undef GNL_RUN
   return done();
 }

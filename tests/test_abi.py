@@ -64,3 +64,24 @@ def test_package_does_not_import_oracle():
     code = ("import sys; import elasticdiffusion_official_amd as p; from elasticdiffusion_official_amd import pipeline, ops, "
             "geometry, host_rng, schedule, sharding; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=_hip.ROOT_DIR)
+
+
+def test_every_kernel_defined_is_launched():
+    """Static check of the .hip sources: every ``__global__`` kernel is referenced from live host code -- directly or through a
+    launch macro that is actually expanded somewhere.  (A dispatch macro that was defined but never expanded once left an
+    entry point returning success without launching anything; a container without a GPU cannot notice that at run time.)"""
+    dead = []
+    for src in _hip.SOURCES:
+        text = re.sub(r"\\\n", " ", open(src).read())                                     # join macro continuation lines
+        for m in re.finditer(r"^#define\s+(\w+)\(([^)]*)\)(.*)$", text, flags=re.M):
+            name, body = m.group(1), m.group(3)
+            rest = text[:m.start()] + text[m.end():]
+            if ("<<<" in body or "LAUNCH" in body) and not re.search(r"\b%s\s*\(" % name, rest):
+                dead.append(name)
+                text = rest                                                                   # its body launches nothing
+        defined = set(re.findall(r"__global__[^;{]*?\b(k_\w+)\s*\(", text, flags=re.S))
+        assert defined, src
+        for k in sorted(defined):
+            uses = len(re.findall(r"\b%s\b" % k, text))
+            assert uses >= 2, f"{k} in {src} is defined but never launched"
+    assert not dead, f"launch macros never expanded: {dead}"

@@ -236,10 +236,16 @@ def test_make_grid_matches_torchvision_layout():
 
 def test_flash_variant_heuristic():
     from elasticdiffusion_official_amd import ops
-    assert ops._flash_variant(20, 10, 4096, 4096) == 2   # SDXL level-2 self attention at batch 20: 64 rows per wave
-    assert ops._flash_variant(20, 20, 1024, 1024) == 0   # level 3
-    assert ops._flash_variant(20, 10, 4096, 77) == 0     # cross attention
-    assert ops._flash_variant(1, 10, 4096, 4096) == 0    # too few workgroups to fill the chip with 256-row blocks
+    # round 3 (profiles/r3_s2_probe_attn.jsonl): the pipelined kernel wins or ties on every self-attention shape, the
+    # small-KV kernel on the 77-token cross attention
+    assert ops._flash_variant(20, 10, 4096, 4096) == 4   # SDXL level-2 self attention
+    assert ops._flash_variant(20, 20, 1024, 1024) == 4   # level 3
+    assert ops._flash_variant(20, 10, 4096, 77) == 8     # cross attention (Nk <= 96)
+    assert ops._flash_variant(1, 10, 4096, 100) == 0     # neither: one full tile + a ragged one
+    class _Strided:   # stand-in for a k / v tensor with a huge token stride: 32-bit K offsets would overflow -> round-2 kernel
+        def stride(self, dim):
+            return 2 ** 20
+    assert ops._flash_variant(20, 10, 4096, 4096, _Strided(), _Strided()) == 2
     saved = ops.FLASH_V_PATH
     try:
         ops.FLASH_V_PATH = 1

@@ -68,8 +68,8 @@ def main():
           f"({len(ufdb)} / {len(udb)} records in total)")
 
 
-if __name__ == "__main__":
-    main()
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "borrow"):
+    main()  # `miopen_nhwc_from_nchw.py borrow FP16` runs only the second step, for that dtype
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -95,13 +95,15 @@ def _parse_udb_key(k):
                 pad=(f[10], f[11]), stride=(f[13], f[14]), layout=f[21], dtype=f[22], fields=f)
 
 
-def borrow_ck_instances():
+def borrow_ck_instances(dtype="BF16"):
+    """``dtype`` = "BF16" or "FP16" (round 3: the fp16 UNet's records come from a find pass at batch 20 / 6; the per-rank
+    batches of row sharding -- 10, 3, ... -- borrow from them exactly as the bf16 ones did)."""
     udb_path = glob.glob(os.path.join(CACHE, "*.udb.txt"))[0]
     ufdb_path = glob.glob(os.path.join(CACHE, "*.ufdb.txt"))[0]
     udb, ufdb = read(udb_path), read(ufdb_path)
     donors = {}  # (cin, cout, kh, kw, stride, pad) -> list of (H, W, n, instance)
     for k, v in udb.items():
-        if "xBF16xF" not in k:
+        if f"x{dtype}xF" not in k:
             continue
         p = _parse_udb_key(k)
         inst = [r for r in v.split(";") if r.startswith(CK + ":")]
@@ -111,7 +113,9 @@ def borrow_ck_instances():
     # every distinct bf16 convolution shape the find-db has seen (either layout, any batch)
     shapes = set()
     for k in ufdb:
-        if not k.endswith("-BF16-F"):
+        # every 16-bit convolution shape the find-db has seen in EITHER 16-bit dtype is wanted for this dtype (the fp16
+        # find pass of round 3 covered only the headline workload; SD1.5's and cfg4's shapes were seen in bf16)
+        if not (k.endswith(f"-{dtype}-F") or k.endswith("-BF16-F")):
             continue
         f = k.split("-")
         cin, H, W, kk, cout, Ho, Wo, n, pad, stride = f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9]
@@ -129,15 +133,15 @@ def borrow_ck_instances():
         inst = min(cand, key=lambda c: ((c[0], c[1]) != (H, W), abs(c[0] * c[1] - H * W), abs(c[2] - n)))[3]
         for layout in ("NHWC", "NCHW"):
             key = "x".join(str(v) for v in (2, cin, H, W, 1, kh, kw, 1, cout, n, pad[0], pad[1], 0, stride[0], stride[1], 0,
-                                            1, 1, 0, 0, 1, layout, "BF16", "F"))
+                                            1, 1, 0, 0, 1, layout, dtype, "F"))
             cur = udb.get(key, "")
             if (CK + ":") in cur:
                 continue
             udb[key] = (cur + ";" if cur else "") + inst
             added += 1
     write(udb_path, udb)
-    print(f"{added} borrowed CK perf-db records written ({len(udb)} records in total)")
+    print(f"{added} borrowed {dtype} CK perf-db records written ({len(udb)} records in total)")
 
 
 if __name__ == "__main__":
-    borrow_ck_instances()
+    borrow_ck_instances(sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "borrow" else "BF16")

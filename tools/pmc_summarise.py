@@ -13,7 +13,9 @@ import re
 import sys
 from collections import defaultdict
 
-ENTRY = {"k_flash_attn_fwd": "ed_flash_attention", "k_geglu": "ed_geglu", "k_groupnorm": "ed_groupnorm",
+ENTRY = {"k_flash_attn_fwd": "ed_flash_attention", "k_flash_attn_pipe": "ed_flash_attention",
+         "k_flash_attn_smallkv": "ed_flash_attention", "k_bias_residual_add_cl": "ed_bias_residual_add",
+         "k_softmax_rows_f32": "ed_softmax_rows", "k_geglu": "ed_geglu", "k_groupnorm": "ed_groupnorm",
          "k_gn_split_stats": "ed_groupnorm[split stats]", "k_gn_split_apply": "ed_groupnorm[split apply]",
          "k_gn_nhwc_partial": "ed_groupnorm_nhwc[partial]", "k_gn_nhwc_apply": "ed_groupnorm_nhwc[apply]",
          "k_add_layernorm": "ed_add_layernorm", "k_layernorm": "ed_layernorm", "k_tokens_add_nchw": "ed_tokens_add_nchw",
@@ -52,6 +54,6 @@ for e, counters in vals.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in r and "SQ_BUSY_CU_CYCLES_mean" in r and r["SQ_BUSY_CU_CYCLES_mean"]:
         r["mfma_busy_over_cu_busy"] = round(r["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / r["SQ_BUSY_CU_CYCLES_mean"], 4)
     res[e] = r
-json.dump({"note": __doc__.strip().split("usage")[0].strip() + " Launch mix: one phase-A (20-row) and one phase-B (6-row) "
+json.dump({"workload": "sdxl_1024x2048", "note": __doc__.strip().split("usage")[0].strip() + " Launch mix: one phase-A (20-row) and one phase-B (6-row) "
                    "SDXL forward of the 1024x2048 workload (tools/pmc_unet.py).", "kernels": res}, open(out_path, "w"), indent=1)
 print(json.dumps({k: {c: round(v, 1) if isinstance(v, float) else v for c, v in r.items()} for k, r in res.items()}, indent=1))

@@ -15,9 +15,9 @@ cfg = pipe.unet.config
 with torch.no_grad():
     for rep in range(2):  # first repetition warms (kernel load, fused weights); rocprofv3 sees both, the summary skips it
         for rows in (20, 6):
-            x = torch.randn(rows, 4, 128, 128, device="cuda", dtype=torch.bfloat16)
-            txt = torch.randn(rows, 77, cfg.cross_attention_dim, device="cuda", dtype=torch.bfloat16)
-            pl = torch.randn(rows, cfg.pooled_projection_dim, device="cuda", dtype=torch.bfloat16)
+            x = torch.randn(rows, 4, 128, 128, device="cuda", dtype=pipe.model_dtype)
+            txt = torch.randn(rows, 77, cfg.cross_attention_dim, device="cuda", dtype=pipe.model_dtype)
+            pl = torch.randn(rows, cfg.pooled_projection_dim, device="cuda", dtype=pipe.model_dtype)
             pipe._forward_rows(x, torch.tensor(500, device="cuda"), txt, pl, None)
         torch.cuda.synchronize()
 print("done")

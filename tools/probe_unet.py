@@ -26,7 +26,7 @@ if os.environ.get("ED_SCGEMM", "1") == "0":
 if os.environ.get("ED_CL", "0") == "1":
     M.CHANNELS_LAST = True
 cfg = M.UNET_CONFIGS[fam]
-dt = torch.bfloat16
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("ED_DTYPE", "bf16")]
 torch.manual_seed(0)
 unet = M.UNet2DConditionModel(**cfg).to("cuda", dt).eval().requires_grad_(False)
 if M.CHANNELS_LAST:
@@ -43,4 +43,4 @@ for B in batches:
     t0 = time.perf_counter()
     with torch.no_grad():
         dtm = bench(lambda: unet(x, t, encoder_hidden_states=e, added_cond_kwargs=kw))
-    print(f"{fam} cl={M.CHANNELS_LAST} ln={M.FUSED_LAYERNORM} fused={M.FUSED_KERNELS} scgemm={M.SHORTCUT_AS_GEMM} benchmark={torch.backends.cudnn.benchmark} B={B:2d}: {dtm*1e3:8.1f} ms  {dtm*1e3/B:7.1f} ms/sample  {B*flops/dtm/1e12:7.1f} TFLOP/s  (wall incl. first call {time.perf_counter()-t0:.1f}s)", flush=True)
+    print(f"{fam} {os.environ.get('ED_DTYPE', 'bf16')} cl={M.CHANNELS_LAST} ln={M.FUSED_LAYERNORM} fused={M.FUSED_KERNELS} scgemm={M.SHORTCUT_AS_GEMM} benchmark={torch.backends.cudnn.benchmark} B={B:2d}: {dtm*1e3:8.1f} ms  {dtm*1e3/B:7.1f} ms/sample  {B*flops/dtm/1e12:7.1f} TFLOP/s  (wall incl. first call {time.perf_counter()-t0:.1f}s)", flush=True)
