@@ -17,7 +17,7 @@ SOURCES = [os.path.join(PKG_DIR, "csrc", n) for n in ("elastic_kernels.hip", "un
 SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT_DIR, "include")
 SO_PATH = os.path.join(PKG_DIR, "libelastic_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -54,6 +54,8 @@ SIGNATURES = {
                           _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _f,
                           _vp],
     "ed_softmax_rows": [_vp, _i64, _i64, _f, _vp],
+    "ed_groupnorm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "ed_groupnorm_f32_workspace": [_i, _i, _i, _i],
     "ed_flash_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp],
 }
 

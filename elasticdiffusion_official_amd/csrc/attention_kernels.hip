@@ -601,6 +601,9 @@ k_flash_attn_pipe(const Params p) {
 
   if (n_full > 0) {
     qk_tile<T>(sm.k[0], ln, hi, qf, sA);
+    // tile 0's iteration ends by overwriting sm.k[0] with tile 2: every wave must be done with the reads above first (inside
+    // the loop the barrier that closes iteration t-1 plays that role for the buffer iteration t overwrites)
+    __syncthreads();
     if (n_full == 1) {
       iter(False{}, False{}, 0, sA, sB, pB, pA);
     } else {

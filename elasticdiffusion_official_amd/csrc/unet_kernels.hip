@@ -765,6 +765,100 @@ k_bias_residual_add_cl(const uint16_t* __restrict__ h, const uint16_t* __restric
   }
 }
 
+// ---- GroupNorm (+SiLU), fp32, NCHW: the VAE's normalisation layers ----------------------------------------------------
+// torch's fp32 GroupNorm is one 501 us `RowwiseMomentsCUDAKernel` per call on the pad-strip encodes (ONE block per (sample,
+// group): 160 blocks for a [5,128,256,1024] activation on a 256-CU chip, 1.3 TB/s) + an affine kernel + a separate SiLU kernel
+// (profiles/r3_s3_bench_*: 610 ms per two images).  Here: (1) partial sums over 64 K-element chunks of every group -- all CUs
+// busy, four 16-byte loads in flight per thread -- and (2) an apply pass whose blocks first combine their group's partials in
+// double (fixed order: deterministic), then stream y = silu((x - mean) * rstd * gamma[c] + beta[c]).
+#define GN32_THREADS 256
+#define GN32_CHUNK 65536  // elements per block
+
+__global__ void __launch_bounds__(GN32_THREADS)
+k_gn32_partial(const float* __restrict__ x, float* __restrict__ partial, int64_t group_len, int nchunks) {
+  __shared__ double red[2 * (GN32_THREADS / 64)];
+  const int64_t ng = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const float* base = x + ng * group_len;
+  const int64_t e0 = (int64_t)chunk * GN32_CHUNK, e1 = e0 + GN32_CHUNK < group_len ? e0 + GN32_CHUNK : group_len;
+  float s = 0.f, q = 0.f;
+  int64_t i = e0 + 4 * (int64_t)threadIdx.x;
+  const int64_t step = 4 * GN32_THREADS;
+  for (; i + 3 * step + 3 < e1; i += 4 * step) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + i + u * step);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      q += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+    }
+  }
+  for (; i + 3 < e1; i += step) {
+    const float4 v = *reinterpret_cast<const float4*>(base + i);
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  double ds = (double)s, dq = (double)q;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ds += __shfl_xor(ds, off, 64);
+    dq += __shfl_xor(dq, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) red[2 * (threadIdx.x >> 6)] = ds, red[2 * (threadIdx.x >> 6) + 1] = dq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+#pragma unroll
+    for (int w = 0; w < GN32_THREADS / 64; ++w) ts += red[2 * w], tq += red[2 * w + 1];
+    float* dst = partial + (ng * nchunks + chunk) * 2;
+    dst[0] = (float)ts, dst[1] = (float)tq;
+  }
+}
+
+template <bool ACT>
+__global__ void __launch_bounds__(GN32_THREADS)
+k_gn32_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+             const float* __restrict__ partial, float* __restrict__ out, int64_t group_len, int HW, int cpg, int G,
+             int nchunks, float eps) {
+  __shared__ float st[2];
+  const int64_t ng = blockIdx.y;
+  const int chunk = blockIdx.x;
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    const float* p = partial + ng * nchunks * 2;
+    for (int c = 0; c < nchunks; ++c) ts += (double)p[2 * c], tq += (double)p[2 * c + 1];
+    const double mean = ts / (double)group_len;
+    double var = tq / (double)group_len - mean * mean;
+    if (var < 0.0) var = 0.0;
+    st[0] = (float)mean, st[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = st[0], rstd = st[1];
+  const int g = (int)(ng % G);
+  const float* base = x + ng * group_len;
+  float* obase = out + ng * group_len;
+  const int64_t e0 = (int64_t)chunk * GN32_CHUNK, e1 = e0 + GN32_CHUNK < group_len ? e0 + GN32_CHUNK : group_len;
+  const int64_t step = 4 * GN32_THREADS;
+  auto norm = [&](const float4& v, int64_t e) {  // HW % 4 == 0: the four elements share one channel
+    const int c = g * cpg + (int)(e / HW);
+    const float a = rstd * gamma[c], b = fmaf(-a, mean, beta[c]);
+    float4 o;
+    o.x = fmaf(a, v.x, b), o.y = fmaf(a, v.y, b), o.z = fmaf(a, v.z, b), o.w = fmaf(a, v.w, b);
+    if (ACT) o.x = silu(o.x), o.y = silu(o.y), o.z = silu(o.z), o.w = silu(o.w);
+    return o;
+  };
+  int64_t i = e0 + 4 * (int64_t)threadIdx.x;
+  for (; i + 3 * step + 3 < e1; i += 4 * step) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + i + u * step);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(obase + i + u * step) = norm(v[u], i + u * step);
+  }
+  for (; i + 3 < e1; i += step) *reinterpret_cast<float4*>(obase + i) = norm(*reinterpret_cast<const float4*>(base + i), i);
+}
+
 // ---- row softmax, fp32, in place: x[r, :] = softmax(scale * x[r, :]) ---------------------------------------------------
 // The VAE mid-block attention (one head of dim 512 over up to 32768 tokens, fp32 like the rest of the VAE: ED:328 keeps
 // the encoder out of autocast, the decoder runs after it, ED:1080-1121) as  S = Q K^T (fp32 GEMM) -> this kernel -> S V
@@ -1052,6 +1146,34 @@ int ed_tokens_add_nchw(const void* x, const void* tokens, void* out, int dtype, 
     k_tokens_add_nchw<F16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)tokens, (uint16_t*)out, C, HW);
   else
     return (int)hipErrorInvalidValue;
+  return done();
+}
+
+int64_t ed_groupnorm_f32_workspace(int N, int C, int HW, int G) {
+  if (G <= 0 || C % G) return 0;
+  const int64_t group_len = (int64_t)(C / G) * HW;
+  const int64_t nchunks = (group_len + GN32_CHUNK - 1) / GN32_CHUNK;
+  return (int64_t)N * G * nchunks * 2 * (int64_t)sizeof(float);
+}
+
+int ed_groupnorm_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW,
+                     int G, float eps, int act_silu, void* stream) {
+  if (N == 0) return 0;
+  if (G <= 0 || C % G != 0 || HW % 4 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u) || (int64_t)N * G > 0x7fffffffll / 2)
+    return (int)hipErrorInvalidValue;
+  const int cpg = C / G;
+  const int64_t group_len = (int64_t)cpg * HW;
+  const int64_t nchunks = (group_len + GN32_CHUNK - 1) / GN32_CHUNK;
+  if (nchunks > 65535 * 16) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)nchunks, (unsigned)((int64_t)N * G));
+  k_gn32_partial<<<grid, GN32_THREADS, 0, s>>>((const float*)x, workspace, group_len, (int)nchunks);
+  if (act_silu)
+    k_gn32_apply<true><<<grid, GN32_THREADS, 0, s>>>((const float*)x, (const float*)gamma, (const float*)beta, workspace,
+                                                    (float*)out, group_len, HW, cpg, G, (int)nchunks, eps);
+  else
+    k_gn32_apply<false><<<grid, GN32_THREADS, 0, s>>>((const float*)x, (const float*)gamma, (const float*)beta, workspace,
+                                                     (float*)out, group_len, HW, cpg, G, (int)nchunks, eps);
   return done();
 }
 

@@ -71,6 +71,10 @@ def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=
     if _fusable(x) and (H * W) % 8 == 0 and (not tokens or cpg % 4 == 0):
         from . import ops
         return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, tokens=tokens)
+    if (VAE_HIP_GROUPNORM and FUSED_KERNELS and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not tokens
+            and (H * W) % 4 == 0 and norm.weight.dtype == torch.float32):
+        from . import ops  # the fp32 VAE: split statistics + apply (+SiLU) instead of torch's one-block-per-group moments
+        return ops.groupnorm_f32(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
     y = F.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps)
     if silu:
         y = F.silu(y)
@@ -84,6 +88,7 @@ FUSED_ADD_LAYERNORM = True  # BasicTransformerBlock: residual add + next LayerNo
 FUSED_TOKENS_ADD = True     # Transformer2DModel: tokens -> NCHW + residual in one kernel (ed_tokens_add_nchw)
 FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit) instead of SDPA / AOTriton
 FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
+VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels
 VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_rows + fp32 GEMM instead of SDPA (AOTriton)
 # A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
 for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
@@ -588,7 +593,7 @@ class _VaeAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        h = self.group_norm(x).view(B, C, H * W).transpose(1, 2)
+        h = group_norm_act(self.group_norm, x).view(B, C, H * W).transpose(1, 2)
         if VAE_HIP_ATTENTION and h.is_cuda and h.dtype == torch.float32 and (H * W) % 4 == 0:
             # two fp32 library GEMMs around ed_softmax_rows: no AOTriton (Triton) kernel on the path
             from . import ops
@@ -650,7 +655,7 @@ class _Encoder(nn.Module):
         x = self.conv_in(x)
         for b in self.down_blocks:
             x = b(x)
-        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+        return self.conv_out(group_norm_act(self.conv_norm_out, self.mid_block(x), silu=True))
 
 
 class _Decoder(nn.Module):
@@ -671,7 +676,7 @@ class _Decoder(nn.Module):
         x = self.mid_block(self.conv_in(z))
         for b in self.up_blocks:
             x = b(x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(group_norm_act(self.conv_norm_out, x, silu=True))
 
 
 class DiagonalGaussian:

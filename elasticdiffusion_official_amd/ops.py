@@ -425,6 +425,21 @@ def tokens_add_nchw(x, tokens):
     return out
 
 
+def groupnorm_f32(x, gamma, beta, groups, eps, silu=False):
+    """x fp32 [N,C,H,W] NCHW-contiguous -> GroupNorm(+SiLU), fp32 (the VAE's normalisation layers; ed_groupnorm_f32)."""
+    N, C, H, W = x.shape
+    if (H * W) % 4:
+        _reject("groupnorm_f32: H*W must be a multiple of 4")
+    out = torch.empty_like(x)
+    nbytes = _hip.lib().ed_groupnorm_f32_workspace(N, C, H * W, groups)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=x.device)
+    TIMER.note_work("ed_groupnorm_f32", nbytes=3.0 * x.numel() * 4)
+    _call("ed_groupnorm_f32", _dev(x, torch.float32, "x"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+          _dev(out, torch.float32, "out"), _dev(ws, torch.float32, "workspace"), N, C, H * W, groups, float(eps), int(silu),
+          _stream())
+    return out
+
+
 def softmax_rows_(x, scale=1.0):
     """x fp32 [..., cols] contiguous -> softmax(scale * x) over the last dim, IN PLACE (ed_softmax_rows)."""
     cols = x.shape[-1]

@@ -302,6 +302,16 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
                        int64_t o_sb, int64_t o_sn, float scale, int v_path, void* stream);
 
 /*
+ * ed_groupnorm_f32 -- GroupNorm (+SiLU) of an fp32 NCHW activation: the VAE's normalisation layers (AutoencoderKL inside
+ * ED:270 decode / ED:350 encode; fp32 like the reference keeps it, ED:328).  HW % 4 == 0.  Two launches: partial sums over
+ * 64 K-element chunks of every (sample, group), then an apply pass whose blocks combine their group's partials in double.
+ *   x, out f32 [N, C, HW]; gamma, beta f32 [C]; workspace: ed_groupnorm_f32_workspace(N, C, HW, G) bytes
+ */
+int64_t ed_groupnorm_f32_workspace(int N, int C, int HW, int G);
+int ed_groupnorm_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW,
+                     int G, float eps, int act_silu, void* stream);
+
+/*
  * ed_softmax_rows -- x[r, :] = softmax(scale * x[r, :]) in place, fp32, rows x cols contiguous (cols % 4 == 0).  The VAE
  * mid-block attention (AutoencoderKL inside ED:270 decode / ED:350 encode; one 512-wide head, fp32) runs as
  * Q K^T (library fp32 GEMM) -> ed_softmax_rows -> S V (library fp32 GEMM) instead of the AOTriton SDPA kernel.

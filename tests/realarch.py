@@ -132,7 +132,7 @@ DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
 # (VERDICT r2 item 1b).  ~5 s of CPU oracle per step.
 LONG_CASES = {
     "cfg3_xl_1024x2048_12steps": dict(sd="XL1.0", H=1024, W=2048, vbs=16, steps=12, R=2, seed=1),
-    "cfg2_sd_512x1024_8steps": dict(sd="1.5", H=512, W=1024, vbs=4, steps=8, R=2, seed=0),
+    "cfg2_sd_512x1024_6steps": dict(sd="1.5", H=512, W=1024, vbs=4, steps=6, R=2, seed=0),
 }
 
 

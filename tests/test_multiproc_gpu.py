@@ -121,9 +121,13 @@ def test_bench_multi_rank_rehearsal(flags):
 
 def _rccl_worker(port, ret):
     """One rank, backend "nccl" (= RCCL on ROCm), every forward forced through the exchange path."""
+    import copy
     import torch.distributed as dist
-    from elasticdiffusion_official_amd import ElasticDiffusion, models
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    from elasticdiffusion_official_amd.sharding import RowSharder
     from tests import realarch as R
+    from tests.fakes import FakeUNet, FakeVAE
+    from tests.test_hip_parity import _embed_fn
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -131,34 +135,40 @@ def _rccl_worker(port, ret):
         ones = torch.ones(1, device="cuda:0")
         dist.all_reduce(ones)
         c = dict(R.REAL_CASES["cfg3_xl_1024x2048"], steps=2, R=1)
-        xl = True
         unet, vae, _ = R.build_small(c["sd"])
         outs = {}
-        for forced in (True, False):
-            pipe = ElasticDiffusion("cuda:0", c["sd"], view_batch_size=c["vbs"], unet=__import__("copy").deepcopy(unet).to(torch.bfloat16),
-                                    vae=__import__("copy").deepcopy(vae), text_encoder=R.embed_fn(xl),
-                                    process_group=None if forced else False)
-            if forced:
-                from elasticdiffusion_official_amd.sharding import RowSharder
-                pipe.sharder = RowSharder(None, force_exchange=True)
-            assert pipe.sharder.exchange == forced and pipe.sharder.world_size == 1
-            pipe.seed_everything(c["seed"])
-            imgs, _ = pipe.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
-                                          resampling_steps=c["R"], output_type="pt", **R.LOOP_KW)
-            outs[forced] = (pipe.last_latents.cpu().numpy(), pipe.sharder.exchanges, pipe._runner.stats())
+        # (a) deterministic fp32 parity models: the exchange must be bit-transparent; (b) the repo's real (reduced-width)
+        # SDXL modules in fp16 -- the production dtype: hipBLASLt's stream-K GEMMs make two 16-bit runs differ at rounding
+        # level even without any exchange, so that pair is compared to the 16-bit noise floor, not bit for bit
+        for kind in ("fake_fp32", "real_fp16"):
+            for forced in (True, False):
+                if kind == "fake_fp32":
+                    mods = dict(unet=FakeUNet(128, xl=True), vae=FakeVAE(), text_encoder=_embed_fn(True))
+                else:
+                    mods = dict(unet=copy.deepcopy(unet).to(torch.float16), vae=copy.deepcopy(vae), text_encoder=R.embed_fn(True))
+                pipe = ElasticDiffusion("cuda:0", c["sd"], view_batch_size=c["vbs"], process_group=None if forced else False, **mods)
+                if forced:
+                    pipe.sharder = RowSharder(None, force_exchange=True)
+                assert pipe.sharder.exchange == forced and pipe.sharder.world_size == 1
+                pipe.seed_everything(c["seed"])
+                imgs, _ = pipe.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                                              resampling_steps=c["R"], output_type="pt", progress=lambda it: it, **R.LOOP_KW)
+                outs[(kind, forced)] = (pipe.last_latents.cpu().numpy(), pipe.sharder.exchanges, pipe._runner.stats(),
+                                        bool(torch.isfinite(imgs).all()))
         ret["ranks_seen"] = int(ones.item())
         ret["backend"] = dist.get_backend()
-        ret["forced"], ret["plain"] = outs[True], outs[False]
+        ret["outs"] = outs
     finally:
         dist.destroy_process_group()
 
 
 def test_rccl_world_size_one_exchange_path():
-    """RCCL itself (backend "nccl") with ONE rank on the test GPU: process-group init, an all-reduce, the bf16
-    ``all_gather_into_tensor`` of every model forward (RowSharder(force_exchange=True)), its stream ordering against the
-    hipGraph replays that produce / consume the exchanged tensors, the fp32 all-gathers of the pad-strip encodes, and
-    ``destroy_process_group`` all execute -- the multi-rank runs on this 1-GPU pool go over gloo, so this is the only
-    place RCCL runs before the driver's 8-GPU box.  The latents must be BIT-identical to the run without the exchange."""
+    """RCCL itself (backend "nccl") with ONE rank on the test GPU: process-group init, an all-reduce, the
+    ``all_gather_into_tensor`` behind every model forward (RowSharder(force_exchange=True); fp32 rows with the parity
+    models, fp16 rows with the real reduced-width SDXL modules), its stream ordering against the hipGraph replays that
+    produce / consume the exchanged tensors, the fp32 all-gathers of the pad-strip units, and ``destroy_process_group`` all
+    execute -- the multi-rank runs on this 1-GPU pool go over gloo, so this is the only place RCCL runs before the
+    driver's 8-GPU box.  With deterministic models the latents are BIT-identical to the run without the exchange."""
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
@@ -166,8 +176,15 @@ def test_rccl_world_size_one_exchange_path():
     p.join(600)
     assert p.exitcode == 0
     assert ret["backend"] == "nccl" and ret["ranks_seen"] == 1
-    zf, n_exchanges, graphs = ret["forced"]
-    zp, n_plain, _ = ret["plain"]
-    assert n_plain == 0 and n_exchanges >= 3 + 2  # (2 steps x 2 phases - 1) model forwards + one gather per pad strip
-    assert graphs["eager"] == 0 and graphs["captured"] >= 1
-    np.testing.assert_array_equal(zf, zp)
+    outs = ret["outs"]
+    for kind in ("fake_fp32", "real_fp16"):
+        zf, n_exchanges, graphs, finite_f = outs[(kind, True)]
+        zp, n_plain, _, finite_p = outs[(kind, False)]
+        assert finite_f and finite_p
+        assert n_plain == 0 and n_exchanges >= 3 + 2  # (2 steps x 2 phases - 1) model forwards + one gather per pad strip
+        assert graphs["eager"] == 0 and graphs["captured"] >= 1
+        if kind == "fake_fp32":
+            np.testing.assert_array_equal(zf, zp)
+        else:
+            rel = float(np.linalg.norm(zf - zp) / np.linalg.norm(zp))
+            assert rel < 0.03, rel   # two fp16 runs of the same loop: ~7e-3 apart (profiles/r3_precision.json "batching_fp16")
