@@ -542,7 +542,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and not args.small:
             out["cpu_baseline"] = guarded(cpu_baseline, pipe, wl, T, fs, V, args.cpu_baseline)
-            full = load_profile_json("r2_cpu_baseline_full.json")
+            full = (load_profile_json("r2_cpu_baseline_full.json") or {}).get("cpu_baseline")
             if isinstance(out["cpu_baseline"], dict) and "error" not in out["cpu_baseline"] and full and \
                     args.workload == "sdxl_1024x2048" and args.cpu_baseline == "bounded":
                 # the bounded sample extrapolates ONE forward-sample; the committed full-mode run (two whole timesteps with

@@ -347,6 +347,7 @@ k_flash_attn_fwd(const Params p) {
 //     (no running state, no rescale), keys >= Nk masked.
 // =====================================================================================================================
 constexpr float RESCALE_LOG2 = 6.0f;  // defer the O rescale until a row's maximum grows by more than 2^6 (exp2 domain)
+constexpr float RESCALE_SUM_MAX = 64.0f;  // = 2^RESCALE_LOG2: the lazy variant's bound on a lane's sum of numerators
 
 struct SmemPipe {
   uint16_t k[2][KT * K_LD];
@@ -459,10 +460,67 @@ __device__ __forceinline__ void softmax_slice(int i, f32x16 (&s)[2], float sl, S
   }
 }
 
+// LAZY variant (v_path 5): after the first tile the per-tile row maximum is not computed at all.  The numerators are taken
+// against the standing reference mb; S is left intact and the only check is on the sum: every numerator is positive, so
+// psum <= 2^RESCALE_LOG2 proves that none of them exceeded 2^RESCALE_LOG2.  When the check fails for any row of the wave
+// (a row's scores grew by more than 2^RESCALE_LOG2 over the reference: rare) the tile's softmax is redone exactly
+// (resoftmax_tile; S is recomputed from the K tile still in LDS) -- 16 v_max3 + the shuffle + the decision arithmetic per tile leave the loop (17 % of its VALU issues,
+// and the max -> exp dependency chain at the head of every tile with them).  Slices: two numerators each, pack at 3, 7, 11, 15.
+template <typename T>
+__device__ __forceinline__ void softmax_slice_lazy(int i, f32x16 (&s)[2], float sl, SoftmaxRun& r, typename T::v8 (&pf)[4]) {
+  if (i == 0) r.psum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int f = 2 * i + j;
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f >> 4][f & 15], sl, -r.mb));
+    s[f >> 4][f & 15] = e;
+    r.psum += e;
+  }
+  asm volatile("" : "+v"(r.psum));
+  if ((i & 3) == 3) {
+    const int g = i >> 2;
+    f32x8 pv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv[j] = s[g >> 1][8 * (g & 1) + j];
+    pf[g] = T::pack(pv);
+    asm volatile("" : "+v"(pf[g]));
+  }
+}
+
+// exact softmax of tile t (the LAZY slow path): S was consumed in place, so it is recomputed from the K tile that is still in
+// LDS (it is overwritten only at the end of the iteration); the reference only ever rises
+template <typename T>
+__device__ __forceinline__ void resoftmax_tile(const uint16_t* kt, int ln, int hi, const typename T::v8 (&qf)[4],
+                                               f32x16 (&s)[2], float sl, SoftmaxRun& r, typename T::v8 (&pf)[4]) {
+  qk_tile<T>(kt, ln, hi, qf, s);
+  float mx = s[0][0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) mx = fmaxf(mx, s[0][j]);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[1][j]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float use = fmaxf(r.mb, mx * sl);
+  r.alpha = __builtin_amdgcn_exp2f(r.mb - use);
+  r.mb = use;
+  float psum = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x8 pv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 8 * g + j;
+      pv[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f >> 4][f & 15], sl, -use));
+      psum += pv[j];
+    }
+    pf[g] = T::pack(pv);
+  }
+  r.psum = psum;
+}
+
 // One loop iteration's compute (see the header comment): 16 MFMAs -- S_next = K(t+1) Q^T, then O += V(t-1)^T P(t-1)^T --
 // each followed by one slice of the softmax of S_cur; the A operand of MFMA i+1 is fetched from LDS before MFMA i is
 // issued.  sched_barrier(0) pins that order (left to itself the scheduler clusters all MFMAs ahead of the softmax).
-template <typename T, bool HAS_PV, bool HAS_NEXT>
+template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY>
 __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16_t* v_prev, int lane, int ln, int hi,
                                             const typename T::v8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
                                             const typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4],
@@ -492,13 +550,14 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
         asm volatile("" : "+v"(o[j & 1]));
       }
     }
-    softmax_slice<T>(i, s_cur, sl, run, p_cur);
+    if (LAZY) softmax_slice_lazy<T>(i, s_cur, sl, run, p_cur);
+    else softmax_slice<T>(i, s_cur, sl, run, p_cur);
     if (i + 1 < N) a_cur = a_nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <typename T>
+template <typename T, bool LAZY>
 __global__ void __launch_bounds__(256, 2)
 k_flash_attn_pipe(const Params p) {
   __shared__ SmemPipe sm;
@@ -583,8 +642,15 @@ k_flash_attn_pipe(const Params p) {
                   typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4]) {
     load_k(t + 2);  // unconditional: a tile past the end reads as zeros (buffer bounds check) into a buffer nobody reads
     load_v(t + 1);
-    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value>(sm.k[(t + 1) & 1], sm.v[vb_prev], lane, ln, hi, qf, s_cur,
-                                                                       s_next, p_prev, p_cur, oacc, sl, run);
+    constexpr bool lazy = LAZY && decltype(has_pv)::value;  // the first tile (no PV yet) always takes the exact softmax
+    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy>(sm.k[(t + 1) & 1], sm.v[vb_prev], lane, ln, hi, qf,
+                                                                             s_cur, s_next, p_prev, p_cur, oacc, sl, run);
+    if (lazy) {
+      run.alpha = 1.0f;
+      if (__any(!(run.psum <= RESCALE_SUM_MAX)))  // (also catches inf / NaN sums)
+        resoftmax_tile<T>(sm.k[t & 1], ln, hi, qf, s_cur, sl, run, p_cur);
+      run.l = __builtin_fmaf(run.l, run.alpha, run.psum);
+    }
     if (__any(run.alpha != 1.0f)) {  // first tile, or a row's maximum grew by more than 2^RESCALE_LOG2 (rare)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -803,10 +869,10 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   Params p;
   p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
   hipStream_t st = (hipStream_t)stream;
-  if (v_path == 4 || v_path == 8) {  // round-3 kernels: 4 = software-pipelined self-attention, 8 = small-KV (Nk <= 96)
+  if (v_path == 4 || v_path == 5 || v_path == 8) {  // round 3: 4 / 5 = software-pipelined (5: lazy maximum), 8 = small-KV
     if (v_path == 8 && Nk > 96) return (int)hipErrorInvalidValue;
     // the pipelined kernel addresses K / V with 32-bit byte offsets from the head's base pointer
-    if (v_path == 4 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
+    if (v_path != 8 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
     const int rows_per_wg = v_path == 8 ? QB * SK_QBLOCKS : QB;
     p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + rows_per_wg - 1) / rows_per_wg;
     p.q_sb = q_sb, p.q_sn = q_sn, p.k_sb = k_sb, p.k_sn = k_sn, p.v_sb = v_sb, p.v_sn = v_sn, p.o_sb = o_sb, p.o_sn = o_sn;
@@ -816,8 +882,11 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
     const dim3 grid((unsigned)nb), block(256);
     if (dtype != ED_BF16 && dtype != ED_F16) return (int)hipErrorInvalidValue;
     if (v_path == 4) {
-      if (dtype == ED_BF16) k_flash_attn_pipe<BF><<<grid, block, 0, st>>>(p);
-      else k_flash_attn_pipe<HF><<<grid, block, 0, st>>>(p);
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF, false><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_pipe<HF, false><<<grid, block, 0, st>>>(p);
+    } else if (v_path == 5) {
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF, true><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_pipe<HF, true><<<grid, block, 0, st>>>(p);
     } else if (Nk <= 64) {
       if (dtype == ED_BF16) k_flash_attn_smallkv<BF, 2><<<grid, block, 0, st>>>(p);
       else k_flash_attn_smallkv<HF, 2><<<grid, block, 0, st>>>(p);

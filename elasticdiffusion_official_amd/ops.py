@@ -474,7 +474,9 @@ def vae_attention(q, k, v):
 # LDS); bit 1 = 64 query rows per wave (256 per workgroup) instead of 32.  None = choose per shape: the 64-row variant is
 # faster only when there is enough work to fill the chip with half as many workgroups (measured, batch 20: N=4096
 # 848 vs 776 TFLOP/s; N=1024 and the 77-key cross attention: no gain or slower; profiles/r2_s7_probe_attn.jsonl)
-# Round 3: 4 = software-pipelined self-attention kernel, 8 = small-KV kernel (Nk <= 96: the 77-token cross attention).
+# Round 3: 4 = software-pipelined self-attention kernel, 5 = the same with the lazy row maximum (no per-tile max after the
+# first tile; exact redo when a lane's sum of numerators exceeds 2^6), 8 = small-KV kernel (Nk <= 96: the 77-token cross
+# attention).
 FLASH_V_PATH = None
 _ENV_VARIANT = __import__("os").environ.get("ED_FLASH_VARIANT")  # A/B: "legacy" = the round-2 choice, or a variant number
 
@@ -487,6 +489,9 @@ def _flash_variant(B, heads, Nq, Nk, k=None, v=None):
         return legacy
     if _ENV_VARIANT is not None:
         want = int(_ENV_VARIANT)
+        if want in (4, 5):
+            fits = k is None or (Nk + 128) * max(k.stride(1), v.stride(1)) * 2 < 2 ** 31
+            return want if (Nk >= 128 and fits) else (8 if Nk <= 96 else legacy)
         return want if (want != 8 or Nk <= 96) else legacy
     if Nk <= 96:
         return 8

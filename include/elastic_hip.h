@@ -293,9 +293,10 @@ int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const flo
  *   v_path: kernel variant.  0 = V transposed on the fly by ds_read_b64_tr_b16, 1 = V^T tile staged in LDS; +2 = 64
  *   query rows per wave (0..3 give bit-identical results).  4 = software-pipelined kernel (softmax of tile t issued in
  *   the shadow of the MFMAs of tiles t+1 / t-1, deferred O rescale; K / V addressed with 32-bit offsets: returns
- *   hipErrorInvalidValue when (Nk + 128) * max(k_sn, v_sn) * 2 >= 2^31).  8 = small-KV kernel for Nk <= 96 (cross
+ *   hipErrorInvalidValue when (Nk + 128) * max(k_sn, v_sn) * 2 >= 2^31).  5 = 4 without the per-tile row maximum after the
+ *   first tile (numerators against the standing reference; exact redo of a tile whose sum exceeds 2^6).  8 = small-KV kernel for Nk <= 96 (cross
  *   attention on the 77 text tokens: K / V staged once per 512 query rows, single pass, no online rescale).
- *   4 and 8 agree with 0..3 to the rounding of P (same fp32 accumulation, different summation grouping).
+ *   4, 5 and 8 agree with 0..3 to the rounding of P (same fp32 accumulation, different summation grouping).
  */
 int ed_flash_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,
                        int head_dim, int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,

@@ -48,7 +48,7 @@ def probe_attn():
         t_sdpa = ev_time(lambda: F.scaled_dot_product_attention(q4, k4, v4))
         res = {"B": B, "H": H, "Nq": Nq, "Nk": Nk, "sdpa_us": round(t_sdpa, 1), "sdpa_tflops": round(flops / t_sdpa / 1e6, 1)}
         ref = ops.flash_attention(q, k, v, H, v_path=0).float()
-        for path in ((0, 8) if Nk <= 96 else (0, 2, 4)):
+        for path in ((0, 8) if Nk <= 96 else (0, 2, 4, 5)):
             t = ev_time(lambda: ops.flash_attention(q, k, v, H, v_path=path))
             res[f"v{path}_us"] = round(t, 1)
             res[f"v{path}_tflops"] = round(flops / t / 1e6, 1)
