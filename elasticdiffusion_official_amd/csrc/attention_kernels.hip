@@ -349,8 +349,11 @@ k_flash_attn_fwd(const Params p) {
 constexpr float RESCALE_LOG2 = 6.0f;  // defer the O rescale until a row's maximum grows by more than 2^6 (exp2 domain)
 constexpr float RESCALE_SUM_MAX = 64.0f;  // = 2^RESCALE_LOG2: the lazy variant's bound on a lane's sum of numerators
 
+// NK = K tile buffers: 2 for the exact kernel; 3 for the LAZY one, whose slow path re-reads K(t) while faster waves of the
+// workgroup already stage K(t+2) (with two buffers that write would land on K(t): a race, seen as wrong results on the GPU)
+template <int NK>
 struct SmemPipe {
-  uint16_t k[2][KT * K_LD];
+  uint16_t k[NK][KT * K_LD];
   uint16_t v[3][KT * V_LD_TR];
 };
 
@@ -560,7 +563,8 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
 template <typename T, bool LAZY>
 __global__ void __launch_bounds__(256, 2)
 k_flash_attn_pipe(const Params p) {
-  __shared__ SmemPipe sm;
+  constexpr int NK = LAZY ? 3 : 2;
+  __shared__ SmemPipe<NK> sm;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, hi = lane >> 5;
@@ -636,6 +640,7 @@ k_flash_attn_pipe(const Params p) {
   f32x16 sA[2], sB[2];
   typename T::v8 pA[4], pB[4];
   int vb_prev = 2, vb_cur = 0, vb_next = 1;  // V buffers of tiles t-1, t, t+1 (mod 3)
+  int kb_cur = 0, kb_next = 1, kb_write = NK == 3 ? 2 : 0;  // K buffers of tiles t, t+1 and the one tile t+2 is staged into
 
   // one full (unmasked) tile t: S_cur holds K(t) Q^T on entry
   auto iter = [&](auto has_pv, auto has_next, int t, f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
@@ -643,12 +648,12 @@ k_flash_attn_pipe(const Params p) {
     load_k(t + 2);  // unconditional: a tile past the end reads as zeros (buffer bounds check) into a buffer nobody reads
     load_v(t + 1);
     constexpr bool lazy = LAZY && decltype(has_pv)::value;  // the first tile (no PV yet) always takes the exact softmax
-    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy>(sm.k[(t + 1) & 1], sm.v[vb_prev], lane, ln, hi, qf,
+    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy>(sm.k[kb_next], sm.v[vb_prev], lane, ln, hi, qf,
                                                                              s_cur, s_next, p_prev, p_cur, oacc, sl, run);
     if (lazy) {
       run.alpha = 1.0f;
       if (__any(!(run.psum <= RESCALE_SUM_MAX)))  // (also catches inf / NaN sums)
-        resoftmax_tile<T>(sm.k[t & 1], ln, hi, qf, s_cur, sl, run, p_cur);
+        resoftmax_tile<T>(sm.k[kb_cur], ln, hi, qf, s_cur, sl, run, p_cur);
       run.l = __builtin_fmaf(run.l, run.alpha, run.psum);
     }
     if (__any(run.alpha != 1.0f)) {  // first tile, or a row's maximum grew by more than 2^RESCALE_LOG2 (rare)
@@ -658,10 +663,12 @@ k_flash_attn_pipe(const Params p) {
         oacc[1][i] *= run.alpha;
       }
     }
-    write_k(t & 1);
+    write_k(kb_write);
     write_v(vb_next);
     const int tmp = vb_prev;
     vb_prev = vb_cur, vb_cur = vb_next, vb_next = tmp;
+    const int ktmp = kb_cur;  // two buffers: (cur, next, write) = (a, b, a) -> (b, a, b); three: a rotation
+    kb_cur = kb_next, kb_next = kb_write, kb_write = NK == 3 ? ktmp : kb_cur;
     __syncthreads();
   };
 
@@ -693,7 +700,7 @@ k_flash_attn_pipe(const Params p) {
 
   if (n_tiles > n_full) {  // ragged last tile: un-pipelined, keys past Nk masked, unconditional rescale
     f32x16 s[2];
-    qk_tile<T>(sm.k[n_full & 1], ln, hi, qf, s);
+    qk_tile<T>(sm.k[kb_cur], ln, hi, qf, s);  // after n_full rotations kb_cur is the buffer of tile n_full
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
