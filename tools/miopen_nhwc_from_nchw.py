@@ -68,7 +68,7 @@ def main():
           f"({len(ufdb)} / {len(udb)} records in total)")
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "borrow"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("borrow", "derive-find")):
     main()  # `miopen_nhwc_from_nchw.py borrow FP16` runs only the second step, for that dtype
 
 
@@ -143,5 +143,50 @@ def borrow_ck_instances(dtype="BF16"):
     print(f"{added} borrowed {dtype} CK perf-db records written ({len(udb)} records in total)")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Third step (round 3): find-db records for the batch sizes that were never searched.
+#
+# Measured in round-3 session 4: when the user find-db has NO record for a problem, MIOpen's immediate mode does not just
+# take a default -- it runs a full find for it on first use (the "30-130 s one-off" of round 2; 113 s for the SDXL UNet at
+# batch 10 in fp16), and eight ranks doing that at once on a shared GPU blew a 15-minute limit.  A find-db record is a
+# ranking of solvers with their times; the ranking of a convolution at one batch size is a sound stand-in for the same
+# convolution at another (the CK solver wins almost everywhere, and its instance comes from the borrowed perf-db record),
+# so every 16-bit channels-last record is copied to the batch sizes of EXTRA_BATCHES that have none, times scaled by the
+# batch ratio.  Real finds (20, 6, 10, 3) are never overwritten.
+# ---------------------------------------------------------------------------------------------------------------------
+def derive_find_records(dtype="FP16"):
+    ufdb_path = glob.glob(os.path.join(CACHE, "*.ufdb.txt"))[0]
+    ufdb = read(ufdb_path)
+    suffix = f"-NHWC-NHWC-NHWC-{dtype}-F"
+    by_shape = {}
+    for k, v in ufdb.items():
+        if not k.endswith(suffix):
+            continue
+        f = k[: -len(suffix)].split("-")
+        if int(f[0]) < 320 and int(f[4]) < 320:
+            continue  # only the full-size UNet / ControlNet convolutions
+        by_shape.setdefault(tuple(f[:7] + f[8:]), []).append((int(f[7]), v))
+    added = 0
+    for shape, recs in by_shape.items():
+        have = {n for n, _ in recs}
+        for n in EXTRA_BATCHES:
+            if n in have:
+                continue
+            n0, v = min(recs, key=lambda r: abs(r[0] - n))
+            out = []
+            for rec in v.split(";"):
+                name, rest = rec.split(":", 1)
+                t, ws, algo = rest.split(",")
+                out.append(f"{name}:{float(t) * n / n0:.6g},{int(int(ws) * n / n0)},{algo}")
+            key = "-".join(list(shape[:7]) + [str(n)] + list(shape[7:])) + suffix
+            ufdb[key] = ";".join(out)
+            added += 1
+    write(ufdb_path, ufdb)
+    print(f"{added} derived {dtype} find-db records written ({len(ufdb)} records in total)")
+
+
 if __name__ == "__main__":
-    borrow_ck_instances(sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "borrow" else "BF16")
+    if len(sys.argv) > 1 and sys.argv[1] == "derive-find":
+        derive_find_records(sys.argv[2] if len(sys.argv) > 2 else "FP16")
+    else:
+        borrow_ck_instances(sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "borrow" else "BF16")
