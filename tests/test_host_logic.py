@@ -268,18 +268,32 @@ def test_miopen_db_derivation_is_idempotent_and_well_formed(tmp_path):
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
     tool.CACHE = work
-    tool.main()
-    tool.borrow_ck_instances()
+    def all_steps():
+        tool.main()
+        tool.borrow_ck_instances()
+        tool.borrow_ck_instances("FP16")
+        tool.derive_find_records("FP16")
+        tool.derive_find_records("BF16")
+
+    all_steps()
     snap = {f: open(f).read() for f in glob.glob(os.path.join(work, "*.txt"))}
-    tool.main()
-    tool.borrow_ck_instances()
+    all_steps()
     assert all(open(f).read() == s for f, s in snap.items())
+    # the committed db already is the fixed point (nothing the product needs is produced only by running the tool here)
+    assert all(open(os.path.join(root, "miopen_cache", os.path.basename(f))).read() == s for f, s in snap.items())
     udb = tool.read(glob.glob(os.path.join(work, "*.udb.txt"))[0])
     k20 = "2x320x128x128x1x3x3x1x320x20x1x1x0x1x1x0x1x1x0x0x1x{}xBF16xF"
     inst = [r for r in udb[k20.format("NCHW")].split(";") if r.startswith(tool.CK)][0]
     assert inst in udb[k20.format("NHWC")]
     assert inst in udb[k20.format("NHWC").replace("x320x20x", "x320x32x")]      # borrowed for cfg4's batch 32
     assert tool.CK in udb["2x320x64x64x1x3x3x1x320x20x1x1x0x1x1x0x1x1x0x0x1xNHWCxBF16xF"]  # SD1.5 shape
+    # round 3: the default fp16 UNet -- real finds at the bench's batches (20, 6) and the per-rank batches of row sharding
+    # (10, 3), perf-db + find-db records (borrowed / derived) for every other batch, so no rank count starts with a find
+    ufdb = tool.read(glob.glob(os.path.join(work, "*.ufdb.txt"))[0])
+    f16 = "320-128-128-3x3-320-128-128-{}-1x1-1x1-1x1-0-NHWC-NHWC-NHWC-FP16-F"
+    for n in (20, 6, 10, 3, 32, 18, 5, 1):
+        assert ufdb[f16.format(n)].startswith(tool.CK), n
+        assert tool.CK in udb[k20.format("NHWC").replace("x320x20x", f"x320x{n}x").replace("BF16", "FP16")], n
 
 
 def test_flash_attention_index_math_emulation():

@@ -56,10 +56,12 @@ def main():
         if not keep:
             continue
         nk = k[: -len("-NCHW-BF16-F")] + "-NHWC-NHWC-NHWC-BF16-F"
+        if nk in ufdb:
+            continue  # a record that is already there (possibly from a real channels-last find) is never overwritten
         ufdb[nk] = ";".join(f"{n}:{t:.6g},{ws},{algo}" for n, (t, ws, algo) in sorted(keep.items(), key=lambda kv: kv[1][0]))
         n_f += 1
     for k, v in list(udb.items()):
-        if k.endswith("xNCHWxBF16xF"):
+        if k.endswith("xNCHWxBF16xF") and (k[: -len("xNCHWxBF16xF")] + "xNHWCxBF16xF") not in udb:
             udb[k[: -len("xNCHWxBF16xF")] + "xNHWCxBF16xF"] = v
             n_p += 1
     write(ufdb_path, ufdb)
