@@ -342,9 +342,9 @@ class ElasticDiffusion(nn.Module):
             draws = [host_rng.strip_draws(dim, side_id, Hs, Ws, t, C) for t in timesteps]
             # The unit of work is one VAE call over ``chunk`` consecutive timesteps, and EVERY call has exactly that
             # batch (the last chunk repeats the final timestep): the convolution shapes MIOpen sees are then the same on
-            # 1, 2, 4 or 8 ranks -- a shape it has not seen costs 30-130 s of one-off kernel builds per process, which
-            # is what round 2's per-rank timestep split (25 -> 21+4 / 13,12 / 7,6 per call) would have paid on the first
-            # real multi-GPU run.  ~16 MiB of fp32 pixels per call, at most STRIP_CHUNK timesteps so that a 50-step
+            # 1, 2, 4 or 8 ranks -- for a shape its find-db has no record of, MIOpen runs a full find on first use (30-130 s
+            # per process), which is what round 2's per-rank timestep split (25 -> 21+4 / 13,12 / 7,6 per call) would have
+            # paid on the first real multi-GPU run.  ~16 MiB of fp32 pixels per call, at most STRIP_CHUNK timesteps so that a 50-step
             # schedule still splits into >= 10 units for 8 ranks.
             chunk = max(1, min(T, STRIP_CHUNK, (16 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
             plans.append((Hs, Ws, y0, x0, chunk, torch.cat([dr[0] for dr in draws]), torch.cat([dr[1] for dr in draws]),
