@@ -359,7 +359,10 @@ def main():
         jobs = [dict(prompts=prompt, negative_prompts=negative, seed=sd_, condition_image=cond_img) for sd_ in seeds]
 
         def on_done(j, z):
-            state["imgs"] = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])
+            # every rank of the shard group holds the finished latent; ONE of them decodes it (round-robin over the group's
+            # ranks), as on one GPU where each image is decoded exactly once -- not g times, once per rank
+            if p.sharder.world_size == 1 or wl["tiled"] or j % p.sharder.world_size == p.sharder.rank:
+                state["imgs"] = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])
 
         kwi = {k: v for k, v in kw.items() if k != "condition_image"}
         p.generate_latents_interleaved(jobs, in_flight=in_flight, on_done=on_done, **kwi)
@@ -510,7 +513,8 @@ def main():
                        "view_batch_size": wl["vbs"], "resampling_steps": R, "views": V, "prompts_per_image": 1,
                        "unet_forward_samples_per_image": fs,
                        "parallelism": (f"{n_groups} shard group(s) x {g}-way row shard (RCCL all-gather per forward), "
-                                       f"{m} image(s) in flight per group; {args.steps} images in total whatever N"),
+                                       f"{m} image(s) in flight per group; {args.steps} images in total whatever N"
+                                       + ("; each finished latent is decoded once, by one rank of its group" if m > 1 else "")),
                        "shard_group": g, "images_in_flight": m,
                        "background_cache": bool(args.cache_backgrounds),
                        "controlnet_conditioning_scale": cn_scale,

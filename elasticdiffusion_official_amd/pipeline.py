@@ -350,25 +350,39 @@ class ElasticDiffusion(nn.Module):
             plans.append((Hs, Ws, y0, x0, chunk, torch.cat([dr[0] for dr in draws]), torch.cat([dr[1] for dr in draws]),
                           torch.cat([dr[2] for dr in draws])))
         coef = coef_host.to(dev)
-        for (Hs, Ws, y0, x0, chunk, colour, post, fwd) in plans:
-            colour, post, fwd = colour.to(dev), post.to(dev), fwd.to(dev)
+        # Strips of the same size (the two strips of a padded axis, unless the pad is odd) form ONE pool of units: 2 x 10
+        # units on 8 ranks split 3,3,3,3,2,2,2,2 instead of 2 x (2,2,1,1,1,1,1,1) -- 15 % of the encodes on the busiest rank
+        # instead of 20 % -- and one exchange per pool instead of one per strip.
+        pools = {}
+        for k, (Hs, Ws, y0, x0, chunk, colour, post, fwd) in enumerate(plans):
+            pools.setdefault((Hs, Ws, chunk), []).append(k)
+        for (Hs, Ws, chunk), members in pools.items():
             n_units = -(-T // chunk)
-            # unit u covers timesteps u*chunk .. u*chunk+chunk-1, clamped to T-1 (the repeats are dropped below)
-            sel_all = torch.arange(n_units * chunk, device=dev).clamp_(max=T - 1).view(n_units, chunk)
+            # draws of the pool's strips back to back: row p*T + t = strip p of the pool at timestep index t
+            colour = torch.cat([plans[k][5] for k in members]).to(dev)
+            post = torch.cat([plans[k][6] for k in members]).to(dev)
+            fwd = torch.cat([plans[k][7] for k in members]).to(dev)
+            # unit (p, u) covers timesteps u*chunk .. u*chunk+chunk-1 of strip p, clamped to T-1 (repeats dropped below)
+            t_idx = torch.arange(n_units * chunk, device=dev).clamp_(max=T - 1).view(n_units, chunk)
+            sel_all = torch.cat([t_idx + p * T for p in range(len(members))])          # [P * n_units, chunk] draw rows
+            t_all = t_idx.repeat(len(members), 1)                                      # ... and their timestep indices
 
-            def encode(sel_rows, *_):
+            def encode(sel_rows, _a, _b, _c, t_rows):
                 """Noised strips of the units ``sel_rows`` [n, chunk] (units are sharded over ranks like model rows)."""
                 outs = []
-                for sel in sel_rows:
+                for sel, tt in zip(sel_rows, t_rows):
                     img = colour[sel][:, :, None, None].expand(chunk, 3, Hs * s, Ws * s).contiguous().to(vae_dtype)
                     dist = self.vae.encode(img).latent_dist
                     enc = (dist.mean.float() + dist.std.float() * post[sel]) * sf
-                    cf = coef[sel]
+                    cf = coef[tt]
                     outs.append(cf[:, 0].view(-1, 1, 1, 1) * enc + cf[:, 1].view(-1, 1, 1, 1) * fwd[sel])
                 return torch.stack(outs)
 
-            strips = self.sharder.run(encode, sel_all, None, None, None, out_like=((chunk, C, Hs, Ws), torch.float32))
-            frames[:, :, y0:y0 + Hs, x0:x0 + Ws] = strips.reshape(n_units * chunk, C, Hs, Ws)[:T]
+            strips = self.sharder.run(encode, sel_all, None, None, None, t_all, out_like=((chunk, C, Hs, Ws), torch.float32))
+            strips = strips.reshape(len(members), n_units * chunk, C, Hs, Ws)
+            for p, k in enumerate(members):
+                y0, x0 = plans[k][2], plans[k][3]
+                frames[:, :, y0:y0 + Hs, x0:x0 + Ws] = strips[p, :T]
         if self.cache_backgrounds:
             self._frame_cache[key] = frames
         return frames
