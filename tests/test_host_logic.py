@@ -315,3 +315,38 @@ def test_flash_attention_index_math_emulation():
         got = emu.run_block(q, k, v, Nq, Nk, 0, 0.125, tr)
         assert sorted(got) == list(range(Nq))
         assert max(np.abs(got[r] - want[r]).max() for r in got) < 1e-12
+
+
+def test_pipelined_attention_schedule_emulation():
+    """tools/emulate_attention_pipeline.py: (1) the pipelined attention kernels' LDS buffer rotation has no interval in
+    which a buffer is both read and written and every read finds its tile -- for the exact kernel (2 K buffers) and the
+    lazy-maximum one (3), while lazy with 2 K buffers is flagged (the race the GPU accuracy tests caught in round 3);
+    (2) the 16-slice softmax, the deferred rescale and the lazy variant's check / slow path reproduce softmax(S) V."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pipe_emu", os.path.join(root, "tools", "emulate_attention_pipeline.py"))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    for n_tiles in range(1, 10):
+        for n_full in (n_tiles, n_tiles - 1):
+            slow = range(1, max(1, n_full))
+            assert emu.lds_hazards(n_tiles, n_full, 2, False) == []
+            assert emu.lds_hazards(n_tiles, n_full, 3, True, slow) == []
+            if n_full >= 2:
+                assert emu.lds_hazards(n_tiles, n_full, 2, True, slow) != []
+    rng = np.random.default_rng(3)
+    slow_total = 0
+    for trial in range(24):
+        n = int(rng.integers(1, 10))
+        sc = rng.normal(size=(n, 64)) * 3.0
+        if trial % 3 == 0 and n > 2:
+            sc[n - 2, 40] += 70.0                      # a late tile far above the reference (other lane of the row)
+        if trial % 3 == 1:
+            sc += np.arange(n)[:, None] * 2.5          # creeping maximum: deferred until it has grown by 2^6
+        v = rng.normal(size=(n, 64, 4))
+        want = emu.reference(sc, v, 0.18)
+        for lazy in (False, True):
+            got, slow_tiles = emu.softmax_schedule(sc, v, 0.18, lazy)
+            assert np.abs(got - want).max() < 1e-12
+            slow_total += slow_tiles
+    assert slow_total > 0   # the slow path was exercised
