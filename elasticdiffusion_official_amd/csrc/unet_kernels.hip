@@ -1159,12 +1159,12 @@ int64_t ed_groupnorm_f32_workspace(int N, int C, int HW, int G) {
 int ed_groupnorm_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW,
                      int G, float eps, int act_silu, void* stream) {
   if (N == 0) return 0;
-  if (G <= 0 || C % G != 0 || HW % 4 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u) || (int64_t)N * G > 0x7fffffffll / 2)
-    return (int)hipErrorInvalidValue;
+  if (G <= 0 || C % G != 0 || HW % 4 != 0 || (((uintptr_t)x | (uintptr_t)out) & 15u) || (int64_t)N * G > 65535)
+    return (int)hipErrorInvalidValue;  // (sample, group) is the grid's y dimension
   const int cpg = C / G;
   const int64_t group_len = (int64_t)cpg * HW;
   const int64_t nchunks = (group_len + GN32_CHUNK - 1) / GN32_CHUNK;
-  if (nchunks > 65535 * 16) return (int)hipErrorInvalidValue;
+  if (nchunks > 0x7fffffffll) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nchunks, (unsigned)((int64_t)N * G));
   k_gn32_partial<<<grid, GN32_THREADS, 0, s>>>((const float*)x, workspace, group_len, (int)nchunks);
