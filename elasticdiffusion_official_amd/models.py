@@ -72,7 +72,7 @@ def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=
         from . import ops
         return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, tokens=tokens)
     if (VAE_HIP_GROUPNORM and FUSED_KERNELS and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not tokens
-            and (H * W) % 4 == 0 and norm.weight.dtype == torch.float32):
+            and (H * W) % 4 == 0 and norm.weight.dtype == torch.float32 and N * norm.num_groups <= 65535):
         from . import ops  # the fp32 VAE: split statistics + apply (+SiLU) instead of torch's one-block-per-group moments
         return ops.groupnorm_f32(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
     y = F.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps)
