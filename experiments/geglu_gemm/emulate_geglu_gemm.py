@@ -1,0 +1,357 @@
+"""Lane-level replay of experiments/geglu_gemm/geglu_gemm.hip on the CPU (numpy): index algebra AND schedule hazards.
+
+The kernel was written with no GPU at hand, so everything that can be checked without one is checked here:
+
+* every expression that turns (workgroup, wave, lane, tile, phase) into a global byte offset, an LDS byte address, an MFMA
+  operand slot or an output address is restated below, one to one with the .hip file (same names), and the whole kernel is
+  replayed lane by lane: LDS-DMA (64 lanes x 16 B to wave-uniform base + 16 lane), swizzled fragment reads,
+  v_mfma_f32_16x16x32 (A[i][k]: lane i + 16 (k >> 3), element k & 7; B[k][j]: lane j + 16 (k >> 3); D[i][j]: lane
+  j + 16 (i >> 2), register i & 3), the epilogue's packed stores.  Inputs are small integers, so x @ W^T is exact in
+  fp32 and the GEMM part is compared bit for bit; the GELU polynomial is compared with erf in float64;
+* the schedule is replayed with the two wave rows half a phase apart (the second one passes one extra barrier first) under
+  the two adversarial timings the hardware allows:
+    "dma_early_read_late": an LDS-DMA lands the moment it is issued, a fragment read samples LDS only at the s_waitcnt
+                           that retires it, and after every DMA issued in that barrier interval (write-after-read races);
+    "dma_late_read_early": an LDS-DMA lands only at the issuing wave's counted vmcnt that retires it (end of that barrier
+                           interval), a fragment read samples LDS the moment it is issued and before anything lands in
+                           its interval (read-after-write races).
+  A schedule that gives the exact result under both is free of LDS races between barrier intervals, whatever the DMA
+  latency.  (`--break war|raw|lgkm` moves one staging step / weakens one wait / drops the early lgkmcnt and shows the replay catching it.)
+
+Run:  python experiments/geglu_gemm/emulate_geglu_gemm.py            (about a minute)
+"""
+import argparse
+import math
+import sys
+
+import numpy as np
+
+BM, BN, BK, SUB, W_REGION, BUF = 256, 128, 64, 1024, 32768, 65536
+
+
+def swz(p):
+    return p ^ (((p >> 9) & 1) << 5)
+
+
+def x_sub(rg, kh):
+    return (rg * 2 + kh) * SUB
+
+
+def w_sub(rg, kh):
+    return W_REGION + (rg * 2 + kh) * SUB
+
+
+LANES = np.arange(64)
+
+
+class Wave:
+    """One wave's registers, DMA queue and pending reads."""
+
+    def __init__(self, blk, wave):
+        self.blk, self.wave = blk, wave
+        self.wrow, self.wcol = wave >> 2, wave & 3
+        lane = LANES
+        ps = swz(16 * lane)
+        srow, skb = ps >> 6, ps & 63
+        rb = blk.K * 2
+        self.x_voff = (blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow) * rb + skb
+        self.x_half = 64 * rb
+        self.w_voff = (blk.n0 + 32 * (wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (wave & 1)) * rb + skb
+        self.w_gate = blk.I * rb
+        rd = swz((lane & 15) * 64 + (lane >> 4) * 16)
+        self.xrd = rd + self.wrow * 8 * (2 * SUB)
+        self.wrd = rd + W_REGION + self.wcol * 2 * (2 * SUB)
+        self.acc = np.zeros((8, 4, 64, 4), np.float64)
+        self.frag = {}        # name -> [64, 8] values
+        self.vmq = []         # outstanding DMAs, oldest first: (lds_byte_base, values[64, 8])
+        self.pending = []     # outstanding fragment reads, oldest first: (name, lds byte addresses[64])
+
+
+class Block:
+    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None):
+        self.x, self.w, self.bias, self.M, self.K, self.I, self.m0, self.n0 = x, w, bias, M, K, I, m0, n0
+        self.mode, self.breakage = mode, breakage
+        self.lds = np.full(2 * BUF // 2, np.nan)      # 16-bit elements; NaN = never written
+        self.waves = [Wave(self, i) for i in range(8)]
+        self.landing = []                               # DMAs retired in this interval (late mode): applied at its end
+
+    # ---- memory side ----------------------------------------------------------------------------------------------
+    def gload(self, which, byte_off):
+        """16 bytes per lane from x (which = 0) or W (1) through a raw buffer: out-of-range reads return zeros."""
+        src = self.x if which == 0 else self.w
+        nbytes = src.size * 2
+        el = byte_off // 2
+        out = np.zeros((64, 8))
+        for l in range(64):
+            if byte_off[l] + 16 <= nbytes:
+                out[l] = src.reshape(-1)[el[l]:el[l] + 8]
+        return out
+
+    def land(self, base, vals):
+        e0 = base // 2
+        self.lds[e0:e0 + 512] = vals.reshape(-1)        # wave-uniform base + 16 bytes x lane
+
+    def dma(self, wv, which, lds_base, voff, soff):
+        if self.pass_ == "rest":
+            return
+        vals = self.gload(which, voff + soff)
+        if self.mode == "dma_early_read_late":
+            self.land(lds_base, vals)
+        wv.vmq.append((lds_base, vals))
+
+    def wait_vm(self, wv, n):
+        if self.pass_ == "issue_dma":
+            return
+        while len(wv.vmq) > n:
+            base, vals = wv.vmq.pop(0)
+            if self.mode == "dma_late_read_early":
+                self.landing.append((base, vals))      # lands no later than this wait; visible to others after the barrier
+
+    def sample(self, addr):
+        a = addr // 2
+        return np.stack([self.lds[a[l]:a[l] + 8] for l in range(64)])
+
+    def read(self, wv, name, addr):
+        if self.pass_ == "issue_dma":
+            return
+        if self.mode == "dma_late_read_early":
+            wv.frag[name] = self.sample(addr)
+        else:
+            wv.pending.append((name, addr))
+
+    def wait_lgkm(self, wv, n):
+        if self.pass_ == "issue_dma":
+            return
+        while len(wv.pending) > n:
+            name, addr = wv.pending.pop(0)
+            wv.frag[name] = self.sample(addr)
+
+    # ---- the kernel's helpers, same names ---------------------------------------------------------------------------
+    def stage_x(self, wv, bufi, tile, h):
+        rg = (wv.wave & 3) + 8 * (wv.wave >> 2) + 4 * h
+        so = tile * (BK * 2) + h * wv.x_half
+        dst = bufi * BUF + x_sub(0, 0) + rg * (2 * SUB)
+        self.dma(wv, 0, dst, wv.x_voff, so)
+        self.dma(wv, 0, dst + SUB, wv.x_voff, so + 64)
+
+    def stage_w(self, wv, bufi, tile, g):
+        rg = 8 * g + wv.wave
+        so = tile * (BK * 2) + g * wv.w_gate
+        dst = bufi * BUF + w_sub(0, 0) + rg * (2 * SUB)
+        self.dma(wv, 1, dst, wv.w_voff, so)
+        self.dma(wv, 1, dst + SUB, wv.w_voff, so + 64)
+
+    def read_x(self, wv, bufi, mh):
+        for mf in range(4):
+            for kh in range(2):
+                self.read(wv, ("x", mf, kh), wv.xrd + bufi * BUF + x_sub(mh * 4 + mf, kh))
+
+    def read_w(self, wv, bufi, g):
+        for nf in range(2):
+            for kh in range(2):
+                self.read(wv, ("wg" if g else "wv", nf, kh), wv.wrd + bufi * BUF + w_sub(8 * g + nf, kh) - W_REGION)
+
+    def mma16(self, wv, mh, g):
+        if self.pass_ == "issue_dma":
+            return
+        assert not wv.pending, "MFMA issued with fragment reads outstanding"
+        for kh in range(2):
+            for mf in range(4):
+                for nf in range(2):
+                    a = wv.frag[("wg" if g else "wv", nf, kh)]      # A operand: [lane, 8]
+                    b = wv.frag[("x", mf, kh)]                      # B operand
+                    A = np.zeros((16, 32))
+                    B = np.zeros((32, 16))
+                    for kg in range(4):
+                        A[:, 8 * kg:8 * kg + 8] = a[16 * kg:16 * kg + 16]
+                        B[8 * kg:8 * kg + 8, :] = b[16 * kg:16 * kg + 16].T
+                    D = A @ B
+                    accv = wv.acc[mh * 4 + mf][g * 2 + nf]
+                    for i in range(16):
+                        accv[16 * (i >> 2):16 * (i >> 2) + 16, i & 3] += D[i, :]
+
+    # ---- program: a list of barrier-separated segments per wave ------------------------------------------------------
+    def tile_segments(self, wv, bufi, tile, s1, s2):
+        brk = self.breakage
+        segs = []
+
+        def ph1a():
+            self.read_w(wv, bufi, 0)
+            self.read_x(wv, bufi, 0)
+            if s1:
+                self.stage_x(wv, bufi ^ 1, tile + 1, 1)
+            if brk == "war" and s2:
+                self.stage_x(wv, bufi, tile + 2, 0)    # BROKEN ON PURPOSE: x m-half 0 re-staged in the phase that reads it
+            if brk != "lgkm":                           # BROKEN ON PURPOSE without it: value rows re-staged one phase later
+                self.wait_lgkm(wv, 8)
+        segs.append(ph1a)
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 0)))
+
+        def ph2a():
+            self.read_w(wv, bufi, 1)
+            if s2:
+                self.stage_w(wv, bufi, tile + 2, 0)
+        segs.append(ph2a)
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 1)))
+
+        def ph3a():
+            self.read_x(wv, bufi, 1)
+            if s2 and brk != "war":
+                self.stage_x(wv, bufi, tile + 2, 0)
+        segs.append(ph3a)
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 1, 1)))
+
+        def ph4a():
+            if s2:
+                self.stage_w(wv, bufi, tile + 2, 1)
+                self.wait_vm(wv, 8 if brk == "raw" else 6)   # BROKEN ON PURPOSE with 8: x m-half 1 of tile + 1 may not have landed
+            else:
+                self.wait_vm(wv, 0)
+        segs.append(ph4a)
+        segs.append(lambda: self.mma16(wv, 1, 0))
+        return segs
+
+    def program(self, wv):
+        nt = self.K // BK
+        segs = []
+
+        def prologue():
+            self.stage_w(wv, 0, 0, 0)
+            self.stage_x(wv, 0, 0, 0)
+            self.stage_w(wv, 0, 0, 1)
+            self.stage_x(wv, 0, 0, 1)
+            if nt > 1:
+                self.stage_w(wv, 1, 1, 0)
+                self.stage_x(wv, 1, 1, 0)
+                self.stage_w(wv, 1, 1, 1)
+                self.wait_vm(wv, 6)
+            else:
+                self.wait_vm(wv, 0)
+        segs.append(prologue)
+        if wv.wrow == 1:
+            segs.append(lambda: None)          # the extra barrier of the second wave row
+        t = 0
+        while t + 1 < nt:
+            segs += self.tile_segments(wv, 0, t, True, t + 2 < nt)
+            segs += self.tile_segments(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
+            t += 2
+        if t < nt:
+            segs += self.tile_segments(wv, 0, t, False, False)
+        if wv.wrow == 0:
+            segs.append(lambda: None)          # pairs the extra barrier
+        return segs
+
+    def run(self):
+        progs = [self.program(wv) for wv in self.waves]
+        n = len(progs[0])
+        assert all(len(p) == n for p in progs), "wave rows execute different numbers of barriers"
+        for seg in range(n):
+            # interval between barrier seg-1 and barrier seg: every wave runs its segment `seg`; order inside an interval is
+            # free on the hardware, the two modes make the adversarial choice (module docstring)
+            if self.mode == "dma_early_read_late":
+                for self.pass_ in ("issue_dma", "rest"):      # every DMA of the interval lands before any read is sampled
+                    for w in range(8):
+                        progs[w][seg]()
+            else:
+                self.pass_ = "all"
+                for w in (range(7, -1, -1) if self.flip else range(8)):
+                    progs[w][seg]()
+                for base, vals in self.landing:   # everything retired in this interval is visible after the barrier
+                    self.land(base, vals)
+                self.landing = []
+        for wv in self.waves:
+            assert not wv.vmq and not wv.pending, "wave ended with loads outstanding"
+
+    pass_ = "all"
+    flip = False
+
+    # ---- epilogue ---------------------------------------------------------------------------------------------------
+    def epilogue(self, out_lin, out):
+        for wv in self.waves:
+            lane = LANES
+            ncol = self.n0 + 32 * wv.wcol + 8 * (lane >> 4)
+            for mb in range(8):
+                m = self.m0 + 128 * wv.wrow + 16 * mb + (lane & 15)
+                for l in range(64):
+                    if m[l] >= self.M:
+                        continue
+                    for nf in range(2):
+                        for j in range(4):
+                            n = ncol[l] + 4 * nf + j
+                            v = wv.acc[mb][nf][l, j] + self.bias[n]
+                            g = wv.acc[mb][2 + nf][l, j] + self.bias[self.I + n]
+                            out_lin[m[l], n] = v
+                            out_lin[m[l], self.I + n] = g
+                            out[m[l], n] = np.float32(v) * gelu_as(np.float32(g))
+
+
+def gelu_as(x):
+    x = np.float32(x)
+    z = np.float32(abs(x)) * np.float32(0.70710678118654752)
+    t = np.float32(1.0) / (np.float32(0.3275911) * z + np.float32(1.0))
+    p = np.float32(1.061405429) * t + np.float32(-1.453152027)
+    p = p * t + np.float32(1.421413741)
+    p = p * t + np.float32(-0.284496736)
+    p = p * t + np.float32(0.254829592)
+    q = p * t * np.float32(2.0) ** (np.float32(-1.4426950408889634) * z * z)
+    h = np.float32(0.5) * x * q
+    return x - h if x > 0 else h
+
+
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-4, 5, size=(M, K)).astype(np.float64)
+    w = rng.integers(-4, 5, size=(2 * I, K)).astype(np.float64)
+    bias = rng.integers(-8, 9, size=2 * I).astype(np.float64) / 4
+    lin = np.full((M, 2 * I), np.nan)
+    out = np.full((M, I), np.nan)
+    nbn = I // BN
+    nb = -(-M // BM) * nbn
+    seen = set()
+    for bid in range(nb):
+        q, r, xcd = nb >> 3, nb & 7, bid & 7
+        tid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (bid >> 3)
+        seen.add(tid)
+        blk = Block(x, w, bias, M, K, I, (tid // nbn) * BM, (tid % nbn) * BN, mode, breakage)
+        blk.flip = flip
+        blk.run()
+        blk.epilogue(lin, out)
+    assert seen == set(range(nb)), "workgroup remap is not a bijection"
+    ref = x @ w.T + bias
+    ok_lin = np.array_equal(lin, ref)
+    gel = 0.5 * ref[:, I:] * (1 + np.vectorize(math.erf)(ref[:, I:] / math.sqrt(2)))
+    want = ref[:, :I] * gel
+    # the polynomial's absolute error (5e-7) is multiplied by the value branch: normalise by it
+    err = np.nanmax(np.abs(out - want) / (1 + np.abs(ref[:, :I]) * (1 + np.abs(ref[:, I:])))) if not np.isnan(out).any() else float("nan")
+    return ok_lin, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm"], default=None)
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    # gelu polynomial against erf, float64
+    xs = np.linspace(-12, 12, 48001)
+    ge = np.array([gelu_as(v) for v in xs], np.float64)
+    gr = 0.5 * xs * (1 + np.vectorize(math.erf)(xs / math.sqrt(2)))
+    print(f"gelu_as vs erf: max abs err {np.abs(ge - gr).max():.3e} (fp16 output ulp at 1.0 is 9.8e-4)")
+    assert np.abs(ge - gr).max() < 2e-6
+    cases = [(300, 192, 256), (256, 64, 128), (512, 256, 128), (256, 640, 128)] if not a.quick else [(300, 256, 128)]
+    bad = 0
+    for (M, K, I) in cases:
+        for mode in ("dma_early_read_late", "dma_late_read_early"):
+            for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
+                ok, err = run_case(M, K, I, mode, flip, a.breakage)
+                verdict = "exact" if ok else "WRONG"
+                print(f"M={M} K={K} ({K // BK} tiles) I={I} {mode:>20s}{' flipped' if flip else ''}: projection {verdict}, "
+                      f"geglu rel err {err:.2e}")
+                bad += (not ok) or not (err < 2e-6)
+    if a.breakage:
+        print("replay", "caught the deliberately broken schedule" if bad else "DID NOT catch the broken schedule")
+        sys.exit(0 if bad else 1)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

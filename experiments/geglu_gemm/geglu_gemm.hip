@@ -1,0 +1,335 @@
+// geglu_gemm.hip -- EXPERIMENT, not part of libelastic_hip.so and not on any product path.
+//
+// Candidate for VERDICT r2 item 4: the transformer feed-forward's first projection with the GEGLU product in the epilogue
+// (diffusers GEGLU.forward: `h, gate = proj(x).chunk(2, -1); return h * gelu(gate)`; the model side of the hot path's
+// boundary, elastic_diffusion.py:422-426 `self.unet(...)`):
+//
+//     out[m, n] = (x[m,:] . W[n,:] + b[n]) * gelu(x[m,:] . W[I+n,:] + b[I+n])        x [M,K], W [2I,K] (torch Linear), out [M,I]
+//
+// It removes `ed_geglu` (598 ms / image in profiles/bench_r3_final_1gpu.json: reads 2I and writes I right after the
+// GEMM wrote 2I).  Written without a GPU at hand (round 3 ended with the GPU budget spent): what HAS been checked is
+// (1) the index algebra -- tools in this directory replay every LDS-DMA destination, swizzle, fragment read, MFMA
+// operand map and store address in numpy and compare the result with x @ W^T, (2) the LDS hazard intervals of the
+// schedule (same tool), (3) the emitted ISA (no spills, the counted waits where the schedule wants them).  What has NOT:
+// one run on hardware.  run_geglu_gemm.py is the harness for that first run.
+//
+// Structure: the 256 x 256 x 64, 8-wave, 8-phase schedule of the CDNA4 guide (cdna_hip_programming.md section 5, "The
+// 256^2 8-phase template"), with the operands arranged for this epilogue:
+//   * a workgroup owns 256 rows of x and 128 VALUE columns + the matching 128 GATE columns of W: a 256 x 256 MFMA tile
+//     whose result is a 256 x 128 tile of `out`;
+//   * wave (wr, wc), wr = wave >> 2, wc = wave & 3: rows [128 wr, +128), value columns [32 wc, +32) and the same gate
+//     columns: 8 x (2 + 2) accumulators of 16 x 16 (128 registers);
+//   * the MFMA is issued as D = W_frag . X_frag^T (A operand = W rows, B operand = x rows), so a lane's 4 accumulator
+//     registers are 4 CONSECUTIVE output columns of ONE row; W rows are staged in the order
+//     n(i, f) = 8 (i >> 2) + (i & 3) + 4 f   (i = MFMA row index, f = fragment 0 / 1), which makes the two fragments of a
+//     lane 8 consecutive columns: one 16-byte store per (lane, 16-row block);
+//   * LDS image = 1-KiB subtiles of 16 rows x 32 k (64-byte rows), rows 8..15 with the two 32-byte halves swapped
+//     (st_16x32 swizzle: conflict-free ds_read_b128 for the 16x16x32 operand layout); a subtile is exactly one
+//     wave-wide LDS-DMA (64 lanes x 16 B), the swizzle is applied to the per-lane SOURCE address and to the read address;
+//   * K tile t lives in buffer t & 1 (2 x 64 KiB: x 32 KiB + W 32 KiB); a tile is consumed in 4 phases of 16 MFMAs
+//     (m half 0 x value, m half 0 x gate, m half 1 x gate, m half 1 x value); one half tile (16 KiB, 2 LDS-DMAs per wave)
+//     is staged per phase, 4..7 phases ahead of its first read; `vmcnt(6)` once per tile, never 0 in the steady state;
+//   * the two wave rows run half a phase apart (the second one passes one extra barrier first): while one issues its
+//     LDS reads and DMAs the other owns the matrix pipe (the two share every SIMD).
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC geglu_gemm.hip -o libgeglu_gemm.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct BF {
+  typedef bf16x8 v8;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+};
+struct HF {
+  typedef f16x8 v8;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+};
+
+constexpr int BM = 256;            // x rows per workgroup
+constexpr int BN = 128;            // value columns per workgroup (+ the same number of gate columns)
+constexpr int BK = 64;             // k per tile
+constexpr int SUB = 1024;          // bytes of one 16-row x 32-k subtile
+constexpr int W_REGION = 32768;    // byte offset of the W subtiles inside a buffer (x: 16 row groups x 2 k halves first)
+constexpr int BUF = 65536;         // bytes per K-tile buffer
+
+// ---- index algebra (mirrored one to one by emulate_geglu_gemm.py) ---------------------------------------------------
+// position p (bytes) inside a subtile <-> element (row, k byte): rows 8..15 have their 32-byte halves swapped
+__device__ __forceinline__ int swz(int p) { return p ^ (((p >> 9) & 1) << 5); }
+// subtile byte offsets inside a buffer
+__device__ __forceinline__ constexpr int x_sub(int rg, int kh) { return (rg * 2 + kh) * SUB; }
+__device__ __forceinline__ constexpr int w_sub(int rg, int kh) { return W_REGION + (rg * 2 + kh) * SUB; }
+
+// gelu(x) = x Phi(x) with erfc from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 on erf): q = erfc(|x| / sqrt 2)
+__device__ __forceinline__ float gelu_as(float x) {
+  const float z = __builtin_fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float q = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float h = 0.5f * x * q;           // x Phi(x) for x < 0
+  return x > 0.f ? x - h : h;             // x (1 - q/2) for x > 0
+}
+
+#define ED_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define ED_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define ED_BARRIER()                          \
+  do {                                        \
+    asm volatile("s_barrier" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);        \
+  } while (0)
+
+struct Ctx {
+  __amdgpu_buffer_rsrc_t xr, wr_;   // buffer descriptors: rows beyond M (or 2I) read as zeros
+  int x_voff, w_voff;               // per-lane byte offsets of the lane's 16 bytes of its wave's subtile (k tile 0, k half 0)
+  int x_half, w_gate;               // bytes from m half 0 to m half 1 (64 rows), from value rows to gate rows (I rows)
+  int wave;                         // wave id (wave-uniform)
+  int xrd, wrd;                     // per-lane LDS byte addresses of fragment (row group 0 of this wave, k half 0), buffer 0
+};
+
+// one half tile = 16 subtiles: wave w fills row group `rg` (both k halves) -- 2 LDS-DMAs of 1 KiB
+template <int BUFI>
+__device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, int tile, int h) {
+  const int rg = (c.wave & 3) + 8 * (c.wave >> 2) + 4 * h;   // rows read in phase 1 (h = 0) / phase 3 (h = 1) of either wave row
+  const int so = tile * (BK * 2) + h * c.x_half;
+  uint8_t* dst = lds + BUFI * BUF + x_sub(0, 0) + rg * (2 * SUB);
+  // the instruction's immediate offset would move the LDS address as well as the memory address: the k half goes in soffset
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, c.x_voff, so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, c.x_voff, so + 64, 0, 0);
+}
+template <int BUFI>
+__device__ __forceinline__ void stage_w(uint8_t* lds, const Ctx& c, int tile, int g) {
+  const int rg = 8 * g + c.wave;                              // value row groups 0..7, gate row groups 8..15
+  const int so = tile * (BK * 2) + g * c.w_gate;
+  uint8_t* dst = lds + BUFI * BUF + w_sub(0, 0) + rg * (2 * SUB);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)dst, 16, c.w_voff, so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)(dst + SUB), 16, c.w_voff, so + 64, 0, 0);
+}
+
+template <class T>
+struct Frags {
+  typename T::v8 x[4][2];    // 4 row blocks of the current m half x 2 k halves   (MFMA B operand)
+  typename T::v8 wv[2][2];   // value fragments f = 0, 1 x 2 k halves              (MFMA A operand)
+  typename T::v8 wg[2][2];   // gate fragments
+};
+
+template <class T, int BUFI>
+__device__ __forceinline__ void read_x(const uint8_t* lds, const Ctx& c, Frags<T>& f, int mh) {
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+      f.x[mf][kh] = *reinterpret_cast<const typename T::v8*>(lds + c.xrd + BUFI * BUF + x_sub(mh * 4 + mf, kh));
+}
+template <class T, int BUFI, int G>
+__device__ __forceinline__ void read_w(const uint8_t* lds, const Ctx& c, Frags<T>& f) {
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      typename T::v8 v = *reinterpret_cast<const typename T::v8*>(lds + c.wrd + BUFI * BUF + w_sub(8 * G + nf, kh) - W_REGION);
+      if (G == 0) f.wv[nf][kh] = v; else f.wg[nf][kh] = v;
+    }
+}
+
+// 16 MFMAs: m half `MH` x (value | gate) x both k halves
+template <class T, int MH, int G>
+__device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const Frags<T>& f) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+        acc[MH * 4 + mf][G * 2 + nf] = T::mfma(G == 0 ? f.wv[nf][kh] : f.wg[nf][kh], f.x[mf][kh], acc[MH * 4 + mf][G * 2 + nf]);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// the four phases of K tile `tile` (buffer BUFI).  s1: tile + 1 exists, s2: tile + 2 exists (wave-uniform).
+template <class T, int BUFI>
+__device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1,
+                                            bool s2) {
+  // ---- phase 1: m half 0 x value.  12 fragment reads: the 4 W reads first, so that lgkmcnt(8) retires them before the
+  // barrier and the value half of this buffer may be re-staged one phase from now.
+  read_w<T, BUFI, 0>(lds, c, f);
+  __builtin_amdgcn_sched_barrier(0);
+  read_x<T, BUFI>(lds, c, f, 0);
+  if (s1) stage_x<BUFI ^ 1>(lds, c, tile + 1, 1);       // x m-half 1 of tile + 1: its buffer's copy was last read 2 phases ago
+  ED_WAIT_LGKM(8);
+  ED_BARRIER();
+  ED_WAIT_LGKM(0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma16<T, 0, 0>(acc, f);
+  ED_BARRIER();
+  // ---- phase 2: m half 0 x gate
+  read_w<T, BUFI, 1>(lds, c, f);
+  if (s2) stage_w<BUFI>(lds, c, tile + 2, 0);           // value rows of tile + 2 (read in phase 1, retired before its barrier)
+  ED_BARRIER();
+  ED_WAIT_LGKM(0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma16<T, 0, 1>(acc, f);
+  ED_BARRIER();
+  // ---- phase 3: m half 1 x gate
+  read_x<T, BUFI>(lds, c, f, 1);
+  if (s2) stage_x<BUFI>(lds, c, tile + 2, 0);           // x m-half 0 of tile + 2 (read in phase 1)
+  ED_BARRIER();
+  ED_WAIT_LGKM(0);
+  __builtin_amdgcn_sched_barrier(0);
+  mma16<T, 1, 1>(acc, f);
+  ED_BARRIER();
+  // ---- phase 4: m half 1 x value (fragments already in registers)
+  if (s2) {
+    stage_w<BUFI>(lds, c, tile + 2, 1);                 // gate rows of tile + 2 (read in phase 2)
+    ED_WAIT_VM(6);                                      // all of tile + 1 has landed; 3 half tiles of tile + 2 stay in flight
+  } else {
+    ED_WAIT_VM(0);                                      // last two tiles: nothing newer to leave in flight
+  }
+  ED_BARRIER();
+  mma16<T, 1, 0>(acc, f);
+  ED_BARRIER();
+}
+
+template <class T>
+__global__ void __launch_bounds__(512, 1)
+k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
+             uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
+
+  // workgroup -> (row block, column block): id b runs on XCD b % 8; give every XCD a contiguous run of tiles, column
+  // blocks fastest, so the 256 x K slab of x it is working on stays in that XCD's L2 (bijective for any grid size)
+  const int bid = blockIdx.x;
+  const int q = n_blocks >> 3, r = n_blocks & 7, xcd = bid & 7;
+  const int tid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int m0 = (tid / n_blocks_n) * BM;
+  const int n0 = (tid % n_blocks_n) * BN;
+
+  const int lane = threadIdx.x & 63;
+  Ctx c;
+  c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wrow = c.wave >> 2, wcol = c.wave & 3;
+
+  // a lane's 16 bytes of a subtile: position 16 lane, element (row, k byte) after the swizzle
+  const int ps = swz(16 * lane), srow = ps >> 6, skb = ps & 63;
+  const int row_bytes = K * 2;
+  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * row_bytes), 0x00020000);
+  c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)2 * I * row_bytes), 0x00020000);
+  c.x_voff = (m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow) * row_bytes + skb;
+  c.x_half = 64 * row_bytes;
+  // LDS row (row group w, row i) of the value / gate half holds W row n0 + 32 (w >> 1) + 8 (i >> 2) + (i & 3) + 4 (w & 1)
+  c.w_voff = (n0 + 32 * (c.wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (c.wave & 1)) * row_bytes + skb;
+  c.w_gate = I * row_bytes;
+  // fragment read: row lane & 15, k bytes 16 (lane >> 4), swizzled; this wave's first row group
+  const int rd = swz((lane & 15) * 64 + (lane >> 4) * 16);
+  c.xrd = rd + wrow * 8 * (2 * SUB);
+  c.wrd = rd + W_REGION + wcol * 2 * (2 * SUB);
+
+  // bias: lane holds columns ncol + 4 f + j (f = fragment, j = accumulator register): 8 consecutive values, one 16-byte load each
+  const int ncol = n0 + 32 * wcol + 8 * (lane >> 4);
+  float bv[2][4], bg[2][4];
+  {
+    u32x4 rv = {0, 0, 0, 0}, rg = {0, 0, 0, 0};
+    if (bias) {
+      rv = *reinterpret_cast<const u32x4*>(bias + ncol);
+      rg = *reinterpret_cast<const u32x4*>(bias + I + ncol);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bv[e >> 2][e & 3] = T::to_f32((uint16_t)(rv[e >> 1] >> (16 * (e & 1))));
+      bg[e >> 2][e & 3] = T::to_f32((uint16_t)(rg[e >> 1] >> (16 * (e & 1))));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)   // consumed here: no ordinary load is pending once the DMAs start
+      asm volatile("" : "+v"(bv[e >> 2][e & 3]), "+v"(bg[e >> 2][e & 3]));
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Frags<T> f;
+
+  const int nt = K / BK;
+  // prologue: all of tile 0, then the three half tiles of tile 1 the loop does not stage itself
+  stage_w<0>(lds, c, 0, 0);
+  stage_x<0>(lds, c, 0, 0);
+  stage_w<0>(lds, c, 0, 1);
+  stage_x<0>(lds, c, 0, 1);
+  if (nt > 1) {
+    stage_w<1>(lds, c, 1, 0);
+    stage_x<1>(lds, c, 1, 0);
+    stage_w<1>(lds, c, 1, 1);
+    ED_WAIT_VM(6);
+  } else {
+    ED_WAIT_VM(0);
+  }
+  ED_BARRIER();
+  if (wrow == 1) ED_BARRIER();    // second wave row runs half a phase behind
+
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile_phases<T, 0>(lds, c, f, acc, t, true, t + 2 < nt);
+    tile_phases<T, 1>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt);
+  }
+  if (t < nt) tile_phases<T, 0>(lds, c, f, acc, t, false, false);
+  if (wrow == 0) ED_BARRIER();    // pair the extra barrier of the second wave row
+
+  // epilogue: one 16-byte store per (lane, 16-row block): 8 consecutive columns of one row
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
+    uint32_t pk[4];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        float o0 = (acc[mb][nf][2 * jj] + bv[nf][2 * jj]) * gelu_as(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
+        float o1 = (acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) * gelu_as(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
+        pk[nf * 2 + jj] = (uint32_t)T::from_f32(o0) | ((uint32_t)T::from_f32(o1) << 16);
+      }
+    if (m < M) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+  }
+}
+
+}  // namespace
+
+// C-ABI of the experiment (would become `ed_geglu_gemm` in include/elastic_hip.h once validated).
+// dtype: 1 = bf16, 2 = f16 (the library's ED_BF16 / ED_F16 codes).  Returns 0 or a hipError_t / -1 for unsupported shapes.
+extern "C" int ed_exp_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I,
+                                 void* stream) {
+  if (M == 0) return 0;
+  if (K % BK != 0 || I % BN != 0 || K < BK) return -1;
+  if (M * (int64_t)K * 2 >= (1ll << 31) || (int64_t)2 * I * K * 2 >= (1ll << 31)) return -1;   // 32-bit buffer offsets
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15u)) return -1;
+  const int nbn = I / BN;
+  const int64_t nb = ((M + BM - 1) / BM) * nbn;
+  if (nb >= (1ll << 31)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == 1)
+    k_geglu_gemm<BF><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M,
+                                            K, I, nbn, (int)nb);
+  else if (dtype == 2)
+    k_geglu_gemm<HF><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M,
+                                            K, I, nbn, (int)nb);
+  else
+    return -1;
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,136 @@
+"""First-run harness for experiments/geglu_gemm/geglu_gemm.hip on an MI355X (needs a GPU; nothing in tests/ or bench.py uses it).
+
+    python experiments/geglu_gemm/run_geglu_gemm.py [--dtype fp16|bf16] [--rounds 7] [--out gpurun_out/geglu_gemm.json]
+
+1. builds libgeglu_gemm.so next to the source when it is missing (hipcc, gfx950);
+2. correctness against an fp32 torch reference of `h, g = (x @ W^T + b).chunk(2, -1); h * gelu(g)` on uniform random
+   [-1, 1) data -- asymmetric by construction, so a transposed operand or store cannot pass -- on a ragged small shape, a
+   one-tile K, an odd tile count and the two SDXL shapes (M = 81 920, K = 640, I = 2560; M = 20 480, K = 1280, I = 5120);
+3. race screen: 20 launches per shape must be bit-identical (the kernel has no atomics and no split-K: any difference
+   between two launches is an LDS race);
+4. timing, interleaved rounds in one process (median and min): this kernel vs the path it would replace
+   (F.linear through hipBLASLt + ed_geglu from libelastic_hip.so), same random data.
+The bar from VERDICT r2 item 4: not slower than hipBLASLt + ed_geglu on the two SDXL shapes.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def build():
+    so = os.path.join(HERE, "libgeglu_gemm.so")
+    src = os.path.join(HERE, "geglu_gemm.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.ed_exp_geglu_gemm.restype = ctypes.c_int
+    lib.ed_exp_geglu_gemm.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                               ctypes.c_void_p]
+    return lib
+
+
+def fused(lib, x, w, b, out):
+    code = 1 if x.dtype == torch.bfloat16 else 2
+    M, K = x.shape
+    I = w.shape[0] // 2
+    rc = lib.ed_exp_geglu_gemm(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(), code, M, K, I,
+                               torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"ed_exp_geglu_gemm returned {rc} for M={M} K={K} I={I}")
+    return out
+
+
+def reference_fp32(x, w, b):
+    y = x.float() @ w.float().t() + (b.float() if b is not None else 0)
+    h, g = y.chunk(2, -1)
+    return h * torch.nn.functional.gelu(g)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    dev = torch.device("cuda:0")
+    lib = build()
+    from elasticdiffusion_official_amd import ops   # the path being replaced: hipBLASLt linear + ed_geglu
+
+    shapes = [(300, 192, 256), (256, 64, 128), (1000, 320, 1280), (81920, 640, 2560), (20480, 1280, 5120), (24576, 640, 2560),
+              (6144, 1280, 5120)]
+    g = torch.Generator(device="cpu").manual_seed(0)
+    report = {"dtype": a.dtype, "shapes": []}
+    ok_all = True
+    for (M, K, I) in shapes:
+        x = (torch.rand(M, K, generator=g) * 2 - 1).to(dev, dt)
+        w = ((torch.rand(2 * I, K, generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
+        b = (torch.rand(2 * I, generator=g) * 2 - 1).to(dev, dt)
+        out = torch.empty(M, I, device=dev, dtype=dt)
+        fused(lib, x, w, b, out)
+        torch.cuda.synchronize()
+        rows = slice(0, min(M, 4096))
+        ref = reference_fp32(x[rows], w, b)
+        unf = ops.geglu(torch.nn.functional.linear(x[rows], w, b), I).float()
+        err = ((out[rows].float() - ref).norm() / ref.norm()).item()
+        err_unfused = ((unf - ref).norm() / ref.norm()).item()
+        maxabs = (out[rows].float() - ref).abs().max().item()
+        first = out.clone()
+        identical = True
+        for _ in range(20):
+            out.zero_()
+            fused(lib, x, w, b, out)
+            identical &= bool(torch.equal(out, first))
+        ok = err < 2e-3 * (4 if dt == torch.bfloat16 else 1) and identical and bool(torch.isfinite(out).all())
+        ok_all &= ok
+        rec = {"M": M, "K": K, "I": I, "rel_l2_vs_fp32": err, "rel_l2_unfused_vs_fp32": err_unfused, "max_abs": maxabs,
+               "bit_identical_20_launches": identical, "ok": ok}
+        if M >= 4096:   # timing A/B
+            y2 = torch.empty(M, 2 * I, device=dev, dtype=dt)
+
+            def unfused():
+                torch.addmm(b, x, w.t(), out=y2)
+                return ops.geglu(y2, I)
+
+            def timed(fn, n=10):
+                fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n
+
+            tf, tu, tl = [], [], []
+            for _ in range(a.rounds):
+                tf.append(timed(lambda: fused(lib, x, w, b, out)))
+                tu.append(timed(unfused))
+                tl.append(timed(lambda: torch.addmm(b, x, w.t(), out=y2)))
+            flops = 2.0 * M * K * 2 * I
+            med = lambda v: sorted(v)[len(v) // 2]
+            rec.update({"fused_ms_median": med(tf), "fused_ms_min": min(tf), "unfused_ms_median": med(tu), "unfused_ms_min": min(tu),
+                        "linear_only_ms_median": med(tl), "fused_tflops_median": flops / med(tf) / 1e9,
+                        "linear_only_tflops_median": flops / med(tl) / 1e9, "speedup_vs_unfused": med(tu) / med(tf)})
+        report["shapes"].append(rec)
+        print(json.dumps(rec), flush=True)
+    report["ok"] = ok_all
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(report, f, indent=1)
+    print("ALL OK" if ok_all else "FAILED")
+    sys.exit(0 if ok_all else 1)
+
+
+if __name__ == "__main__":
+    main()
