@@ -57,7 +57,7 @@ class Wave:
         self.x_voff = (blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow) * rb + skb
         self.x_half = 64 * rb
         self.w_voff = (blk.n0 + 32 * (wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (wave & 1)) * rb + skb
-        self.w_gate = blk.I * rb
+        self.w_gate = blk.gap * rb
         rd = swz((lane & 15) * 64 + (lane >> 4) * 16)
         self.xrd = rd + self.wrow * 8 * (2 * SUB)
         self.wrd = rd + W_REGION + self.wcol * 2 * (2 * SUB)
@@ -68,8 +68,9 @@ class Wave:
 
 
 class Block:
-    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None):
+    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None, epi=0):
         self.x, self.w, self.bias, self.M, self.K, self.I, self.m0, self.n0 = x, w, bias, M, K, I, m0, n0
+        self.epi, self.gap = epi, (I if epi == 0 else BN)
         self.mode, self.breakage = mode, breakage
         self.lds = np.full(2 * BUF // 2, np.nan)      # 16-bit elements; NaN = never written
         self.waves = [Wave(self, i) for i in range(8)]
@@ -278,11 +279,17 @@ class Block:
                     for nf in range(2):
                         for j in range(4):
                             n = ncol[l] + 4 * nf + j
-                            v = wv.acc[mb][nf][l, j] + self.bias[n]
-                            g = wv.acc[mb][2 + nf][l, j] + self.bias[self.I + n]
-                            out_lin[m[l], n] = v
-                            out_lin[m[l], self.I + n] = g
-                            out[m[l], n] = np.float32(v) * gelu_as(np.float32(g))
+                            if self.epi == 0:
+                                v = wv.acc[mb][nf][l, j] + self.bias[n]
+                                g = wv.acc[mb][2 + nf][l, j] + self.bias[self.I + n]
+                                out_lin[m[l], n] = v
+                                out_lin[m[l], self.I + n] = g
+                                out[m[l], n] = np.float32(v) * gelu_as(np.float32(g))
+                            else:
+                                if ncol[l] < self.I:
+                                    out_lin[m[l], n] = wv.acc[mb][nf][l, j] + self.bias[n]
+                                if ncol[l] + self.gap < self.I:
+                                    out_lin[m[l], n + self.gap] = wv.acc[mb][2 + nf][l, j] + self.bias[n + self.gap]
 
 
 def gelu_as(x):
@@ -298,27 +305,37 @@ def gelu_as(x):
     return x - h if x > 0 else h
 
 
-def run_case(M, K, I, mode, flip=False, breakage=None, seed=0):
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0):
+    """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K])."""
     rng = np.random.default_rng(seed)
+    wrows = 2 * I if epi == 0 else I
     x = rng.integers(-4, 5, size=(M, K)).astype(np.float64)
-    w = rng.integers(-4, 5, size=(2 * I, K)).astype(np.float64)
-    bias = rng.integers(-8, 9, size=2 * I).astype(np.float64) / 4
-    lin = np.full((M, 2 * I), np.nan)
+    w = rng.integers(-4, 5, size=(wrows, K)).astype(np.float64)
+    bias = rng.integers(-8, 9, size=wrows).astype(np.float64) / 4
+    lin = np.full((M, wrows), np.nan)
     out = np.full((M, I), np.nan)
-    nbn = I // BN
+    nbn = I // BN if epi == 0 else -(-I // (2 * BN))
     nb = -(-M // BM) * nbn
     seen = set()
     for bid in range(nb):
         q, r, xcd = nb >> 3, nb & 7, bid & 7
         tid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (bid >> 3)
-        seen.add(tid)
-        blk = Block(x, w, bias, M, K, I, (tid // nbn) * BM, (tid % nbn) * BN, mode, breakage)
+        nbm = nb // nbn
+        per_group, = (8 * nbn,)
+        first = (tid // per_group) * 8
+        rows_here = min(nbm - first, 8)
+        rb, cb = first + (tid % per_group) % rows_here, (tid % per_group) // rows_here
+        assert 0 <= rb < nbm and 0 <= cb < nbn
+        seen.add((rb, cb))
+        blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi)
         blk.flip = flip
         blk.run()
         blk.epilogue(lin, out)
-    assert seen == set(range(nb)), "workgroup remap is not a bijection"
+    assert len(seen) == nb, "workgroup remap is not a bijection"
     ref = x @ w.T + bias
     ok_lin = np.array_equal(lin, ref)
+    if epi == 1:
+        return ok_lin, 0.0
     gel = 0.5 * ref[:, I:] * (1 + np.vectorize(math.erf)(ref[:, I:] / math.sqrt(2)))
     want = ref[:, :I] * gel
     # the polynomial's absolute error (5e-7) is multiplied by the value branch: normalise by it
@@ -347,6 +364,12 @@ def main():
                 print(f"M={M} K={K} ({K // BK} tiles) I={I} {mode:>20s}{' flipped' if flip else ''}: projection {verdict}, "
                       f"geglu rel err {err:.2e}")
                 bad += (not ok) or not (err < 2e-6)
+    if not a.breakage and not a.quick:
+        for (M, K, N) in [(300, 128, 640), (256, 192, 200), (256, 64, 256)]:     # plain projection: ragged column blocks
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                ok, _ = run_case(M, K, N, mode, epi=1)
+                print(f"linear M={M} K={K} N={N} {mode:>20s}: projection {'exact' if ok else 'WRONG'}")
+                bad += not ok
     if a.breakage:
         print("replay", "caught the deliberately broken schedule" if bad else "DID NOT catch the broken schedule")
         sys.exit(0 if bad else 1)

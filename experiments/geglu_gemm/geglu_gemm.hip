@@ -207,19 +207,27 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   ED_BARRIER();
 }
 
-template <class T>
+// EPI 0: GEGLU -- W is [2 I, K], the two 128-row halves of the tile are value rows n0.. and gate rows I + n0.., out is [M, I]
+// EPI 1: plain projection + bias -- W is [I, K] (I = output columns), the halves are rows n0.. and n0 + 128.., out is [M, I];
+//        the same main loop, kept so that the schedule can be timed against hipBLASLt on every projection of the block
+template <class T, int EPI>
 __global__ void __launch_bounds__(512, 1)
 k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
              uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
 
-  // workgroup -> (row block, column block): id b runs on XCD b % 8; give every XCD a contiguous run of tiles, column
-  // blocks fastest, so the 256 x K slab of x it is working on stays in that XCD's L2 (bijective for any grid size)
+  // workgroup -> (row block, column block).  Id b runs on XCD b % 8: give every XCD a contiguous run of tile ids, and walk
+  // the ids in groups of 8 row blocks (rows fastest inside a group), so the 32 workgroups an XCD runs at a time are 8 row
+  // blocks x 4 column blocks: 12 operand slabs for 32 tiles in that XCD's L2 instead of 22..34 (bijective for any grid)
   const int bid = blockIdx.x;
   const int q = n_blocks >> 3, r = n_blocks & 7, xcd = bid & 7;
   const int tid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int m0 = (tid / n_blocks_n) * BM;
-  const int n0 = (tid % n_blocks_n) * BN;
+  const int n_blocks_m = n_blocks / n_blocks_n;
+  const int per_group = 8 * n_blocks_n, grp = tid / per_group, first = grp * 8;
+  const int rows_here = n_blocks_m - first < 8 ? n_blocks_m - first : 8;
+  const int m0 = (first + (tid % per_group) % rows_here) * BM;
+  const int n0 = ((tid % per_group) / rows_here) * (EPI == 0 ? BN : 2 * BN);
+  const int gap = EPI == 0 ? I : BN;                 // W rows (= output columns for EPI 1) from the first half to the second
 
   const int lane = threadIdx.x & 63;
   Ctx c;
@@ -230,12 +238,12 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
   const int ps = swz(16 * lane), srow = ps >> 6, skb = ps & 63;
   const int row_bytes = K * 2;
   c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * row_bytes), 0x00020000);
-  c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)2 * I * row_bytes), 0x00020000);
+  c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)(EPI == 0 ? 2 : 1) * I * row_bytes), 0x00020000);
   c.x_voff = (m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow) * row_bytes + skb;
   c.x_half = 64 * row_bytes;
   // LDS row (row group w, row i) of the value / gate half holds W row n0 + 32 (w >> 1) + 8 (i >> 2) + (i & 3) + 4 (w & 1)
   c.w_voff = (n0 + 32 * (c.wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (c.wave & 1)) * row_bytes + skb;
-  c.w_gate = I * row_bytes;
+  c.w_gate = gap * row_bytes;
   // fragment read: row lane & 15, k bytes 16 (lane >> 4), swizzled; this wave's first row group
   const int rd = swz((lane & 15) * 64 + (lane >> 4) * 16);
   c.xrd = rd + wrow * 8 * (2 * SUB);
@@ -247,8 +255,8 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
   {
     u32x4 rv = {0, 0, 0, 0}, rg = {0, 0, 0, 0};
     if (bias) {
-      rv = *reinterpret_cast<const u32x4*>(bias + ncol);
-      rg = *reinterpret_cast<const u32x4*>(bias + I + ncol);
+      if (EPI == 0 || ncol < I) rv = *reinterpret_cast<const u32x4*>(bias + ncol);
+      if (EPI == 0 || ncol + gap < I) rg = *reinterpret_cast<const u32x4*>(bias + gap + ncol);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -296,40 +304,65 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {
     const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
-    uint32_t pk[4];
+    if (EPI == 0) {
+      uint32_t pk[4];
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
+      for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        float o0 = (acc[mb][nf][2 * jj] + bv[nf][2 * jj]) * gelu_as(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
-        float o1 = (acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) * gelu_as(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
-        pk[nf * 2 + jj] = (uint32_t)T::from_f32(o0) | ((uint32_t)T::from_f32(o1) << 16);
-      }
-    if (m < M) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        for (int jj = 0; jj < 2; ++jj) {
+          float o0 = (acc[mb][nf][2 * jj] + bv[nf][2 * jj]) * gelu_as(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
+          float o1 = (acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) * gelu_as(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
+          pk[nf * 2 + jj] = (uint32_t)T::from_f32(o0) | ((uint32_t)T::from_f32(o1) << 16);
+        }
+      if (m < M) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+    } else {
+      uint32_t pv[4], pg[4];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          pv[nf * 2 + jj] = (uint32_t)T::from_f32(acc[mb][nf][2 * jj] + bv[nf][2 * jj]) |
+                            ((uint32_t)T::from_f32(acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) << 16);
+          pg[nf * 2 + jj] = (uint32_t)T::from_f32(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]) |
+                            ((uint32_t)T::from_f32(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]) << 16);
+        }
+      if (m < M && ncol < I) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pv[0], pv[1], pv[2], pv[3]};
+      if (m < M && ncol + gap < I) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol + gap) = u32x4{pg[0], pg[1], pg[2], pg[3]};
+    }
   }
 }
 
 }  // namespace
 
-// C-ABI of the experiment (would become `ed_geglu_gemm` in include/elastic_hip.h once validated).
-// dtype: 1 = bf16, 2 = f16 (the library's ED_BF16 / ED_F16 codes).  Returns 0 or a hipError_t / -1 for unsupported shapes.
-extern "C" int ed_exp_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I,
-                                 void* stream) {
+// C-ABI of the experiment (would become `ed_geglu_gemm` / `ed_linear` in include/elastic_hip.h once validated).
+// dtype: 1 = bf16, 2 = f16 (the library's ED_BF16 / ED_F16 codes).  Returns 0, a hipError_t, or -1 for unsupported shapes.
+//   ed_exp_geglu_gemm: out[M, I] = (x W_v^T + b_v) * gelu(x W_g^T + b_g),   W [2 I, K], I % 128 == 0
+//   ed_exp_linear:     out[M, N] = x W^T + b,                                W [N, K],   N % 8 == 0
+template <int EPI>
+static int launch(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I, void* stream) {
   if (M == 0) return 0;
-  if (K % BK != 0 || I % BN != 0 || K < BK) return -1;
+  if (K % BK != 0 || K < BK || (EPI == 0 ? I % BN != 0 : I % 8 != 0)) return -1;
   if (M * (int64_t)K * 2 >= (1ll << 31) || (int64_t)2 * I * K * 2 >= (1ll << 31)) return -1;   // 32-bit buffer offsets
-  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15u)) return -1;
-  const int nbn = I / BN;
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15u)) return -1;
+  const int nbn = EPI == 0 ? I / BN : (I + 2 * BN - 1) / (2 * BN);
   const int64_t nb = ((M + BM - 1) / BM) * nbn;
   if (nb >= (1ll << 31)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == 1)
-    k_geglu_gemm<BF><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M,
-                                            K, I, nbn, (int)nb);
+    k_geglu_gemm<BF, EPI><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out,
+                                                 (int)M, K, I, nbn, (int)nb);
   else if (dtype == 2)
-    k_geglu_gemm<HF><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M,
-                                            K, I, nbn, (int)nb);
+    k_geglu_gemm<HF, EPI><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out,
+                                                 (int)M, K, I, nbn, (int)nb);
   else
     return -1;
   return (int)hipGetLastError();
+}
+extern "C" int ed_exp_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I,
+                                 void* stream) {
+  return launch<0>(x, w, bias, out, dtype, M, K, I, stream);
+}
+extern "C" int ed_exp_linear(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int N,
+                             void* stream) {
+  return launch<1>(x, w, bias, out, dtype, M, K, N, stream);
 }

@@ -31,9 +31,9 @@ def build():
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
     lib = ctypes.CDLL(so)
-    lib.ed_exp_geglu_gemm.restype = ctypes.c_int
-    lib.ed_exp_geglu_gemm.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
-                                                               ctypes.c_void_p]
+    for fn in (lib.ed_exp_geglu_gemm, lib.ed_exp_linear):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return lib
 
 
@@ -46,6 +46,31 @@ def fused(lib, x, w, b, out):
     if rc != 0:
         raise RuntimeError(f"ed_exp_geglu_gemm returned {rc} for M={M} K={K} I={I}")
     return out
+
+
+def linear(lib, x, w, b, out):
+    code = 1 if x.dtype == torch.bfloat16 else 2
+    rc = lib.ed_exp_linear(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr(), code, x.shape[0],
+                           x.shape[1], w.shape[0], torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"ed_exp_linear returned {rc} for {tuple(x.shape)} x {tuple(w.shape)}")
+    return out
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def med(v):
+    return sorted(v)[len(v) // 2]
 
 
 def reference_fp32(x, w, b):
@@ -100,28 +125,45 @@ def main():
                 torch.addmm(b, x, w.t(), out=y2)
                 return ops.geglu(y2, I)
 
-            def timed(fn, n=10):
-                fn()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(n):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / n
-
             tf, tu, tl = [], [], []
             for _ in range(a.rounds):
                 tf.append(timed(lambda: fused(lib, x, w, b, out)))
                 tu.append(timed(unfused))
                 tl.append(timed(lambda: torch.addmm(b, x, w.t(), out=y2)))
             flops = 2.0 * M * K * 2 * I
-            med = lambda v: sorted(v)[len(v) // 2]
             rec.update({"fused_ms_median": med(tf), "fused_ms_min": min(tf), "unfused_ms_median": med(tu), "unfused_ms_min": min(tu),
                         "linear_only_ms_median": med(tl), "fused_tflops_median": flops / med(tf) / 1e9,
                         "linear_only_tflops_median": flops / med(tl) / 1e9, "speedup_vs_unfused": med(tu) / med(tf)})
         report["shapes"].append(rec)
+        print(json.dumps(rec), flush=True)
+    # the same main loop as a plain projection (out = x W^T + b) on the transformer blocks' other GEMM shapes at batch 20 / 6:
+    # is the schedule itself faster or slower than the hipBLASLt kernels the UNet uses today (43 % of GPU time)?
+    report["linear"] = []
+    for (M, K, N) in [(300, 128, 200), (81920, 640, 1920), (81920, 640, 640), (81920, 2560, 640), (20480, 1280, 3840),
+                      (20480, 1280, 1280), (20480, 5120, 1280), (1540, 2048, 1280), (24576, 640, 1920), (6144, 1280, 3840)]:
+        x = (torch.rand(M, K, generator=g) * 2 - 1).to(dev, dt)
+        w = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
+        b = (torch.rand(N, generator=g) * 2 - 1).to(dev, dt)
+        out = torch.empty(M, N, device=dev, dtype=dt)
+        linear(lib, x, w, b, out)
+        rows = slice(0, min(M, 4096))
+        ref = x[rows].float() @ w.float().t() + b.float()
+        err = ((out[rows].float() - ref).norm() / ref.norm()).item()
+        first = out.clone()
+        identical = all(bool(torch.equal(linear(lib, x, w, b, out.zero_()), first)) for _ in range(10))
+        ok = err < 1e-3 * (8 if dt == torch.bfloat16 else 1) and identical
+        ok_all &= ok
+        rec = {"M": M, "K": K, "N": N, "rel_l2_vs_fp32": err, "bit_identical_10_launches": identical, "ok": ok}
+        if M >= 1024:
+            y = torch.empty(M, N, device=dev, dtype=dt)
+            tm, tl = [], []
+            for _ in range(a.rounds):
+                tm.append(timed(lambda: linear(lib, x, w, b, out)))
+                tl.append(timed(lambda: torch.addmm(b, x, w.t(), out=y)))
+            flops = 2.0 * M * K * N
+            rec.update({"this_ms_median": med(tm), "hipblaslt_ms_median": med(tl), "this_tflops": flops / med(tm) / 1e9,
+                        "hipblaslt_tflops": flops / med(tl) / 1e9})
+        report["linear"].append(rec)
         print(json.dumps(rec), flush=True)
     report["ok"] = ok_all
     if a.out:
