@@ -90,6 +90,11 @@ FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit
 FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
 VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels
 VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_rows + fp32 GEMM instead of SDPA (AOTriton)
+# _VaeAttention's residual: `attn + x` (False, what has been measured: the permuted first operand makes the sum, and so the
+# rest of the encoder / decoder, channels-last -- MIOpen's NHWC fp32 igemm convolutions, torch GroupNorm) or `x + attn`
+# (True: the VAE stays NCHW -- ed_groupnorm_f32 everywhere, MIOpen's NCHW solvers).  Same values bit for bit; the layout
+# is a speed choice that needs its own MIOpen find records, so it stays off until it has been timed on the GPU.
+VAE_NCHW_RESIDUAL = False
 # A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
 for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
     if _name not in globals() or not isinstance(globals()[_name], bool):
@@ -601,7 +606,8 @@ class _VaeAttention(nn.Module):
         else:
             q, k, v = (f(h).unsqueeze(1) for f in (self.to_q, self.to_k, self.to_v))
             o = F.scaled_dot_product_attention(q, k, v).squeeze(1)
-        return self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W) + x
+        a = self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W)
+        return x + a if VAE_NCHW_RESIDUAL else a + x
 
 
 class _VaeMid(nn.Module):
