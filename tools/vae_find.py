@@ -3,7 +3,9 @@
   dec_tiles  decoder, batch 8, latent 128 x 128     (cfg4 tiled decode, ED:275-310, pipeline.tiled_decode tile_batch=8)
   enc_strips encoder, batch 5, pixels 256 x 1024    (SDXL 1024x2048 pad strips, pipeline.STRIP_CHUNK = 5)
   enc_sd15   encoder, batch 5, pixels 128 x 512     (SD1.5 512x1024 pad strips)
-Prints the time per call before (immediate mode, current db) and after the find.   usage: vae_find.py [names...]"""
+Prints the time per call before (immediate mode, current db) and after the find.   usage: vae_find.py [--nchw] [names...]
+--nchw sets models.VAE_NCHW_RESIDUAL (the VAE stays NCHW after the mid-block attention): run once without and
+once with the flag for the A/B -- each layout gets its own find records."""
 import json
 import os
 import sys
@@ -31,7 +33,11 @@ def timed(fn, reps=3):
 
 
 def main():
-    names = sys.argv[1:] or list(CASES)
+    args = sys.argv[1:]
+    if "--nchw" in args:
+        args.remove("--nchw")
+        M.VAE_NCHW_RESIDUAL = True
+    names = args or list(CASES)
     vaes = {}
     with torch.no_grad():
         for name in names:
@@ -51,7 +57,7 @@ def main():
             after_bench = timed(fn)
             torch.backends.cudnn.benchmark = False
             after = timed(fn)   # immediate mode again, now with the find-db records
-            print(json.dumps({"case": name, "shape": list(shape), "before_ms": round(before, 2), "find_s": round(find_s, 1),
+            print(json.dumps({"case": name, "vae_nchw_residual": M.VAE_NCHW_RESIDUAL, "shape": list(shape), "before_ms": round(before, 2), "find_s": round(find_s, 1),
                               "after_benchmark_mode_ms": round(after_bench, 2), "after_immediate_ms": round(after, 2)}), flush=True)
 
 
