@@ -54,10 +54,10 @@ class Wave:
         ps = swz(16 * lane)
         srow, skb = ps >> 6, ps & 63
         rb = blk.K * 2
-        self.x_voff = (blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow) * rb + skb
-        self.x_half = 64 * rb
-        self.w_voff = (blk.n0 + 32 * (wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (wave & 1)) * rb + skb
-        self.w_gate = blk.gap * rb
+        x0 = (blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow) * rb + skb
+        self.x_voff = [x0, x0 + 64 * rb]
+        w0 = (blk.n0 + 32 * (wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (wave & 1)) * rb + skb
+        self.w_voff = [w0, w0 + blk.gap * rb]
         rd = swz((lane & 15) * 64 + (lane >> 4) * 16)
         self.xrd = rd + self.wrow * 8 * (2 * SUB)
         self.wrd = rd + W_REGION + self.wcol * 2 * (2 * SUB)
@@ -77,15 +77,21 @@ class Block:
         self.landing = []                               # DMAs retired in this interval (late mode): applied at its end
 
     # ---- memory side ----------------------------------------------------------------------------------------------
-    def gload(self, which, byte_off):
-        """16 bytes per lane from x (which = 0) or W (1) through a raw buffer: out-of-range reads return zeros."""
+    def gload(self, which, voff, soff):
+        """16 bytes per lane from x (which = 0) or W (1) through a raw buffer.  The range check (zeros when out of range) is modelled
+        on the VGPR offset alone -- the scalar offset may or may not take part in the hardware's check, so the kernel must be
+        right either way: an in-range VGPR offset must give an in-range address (asserted), an out-of-range row must already be
+        out of range by its VGPR offset."""
         src = self.x if which == 0 else self.w
         nbytes = src.size * 2
-        el = byte_off // 2
         out = np.zeros((64, 8))
         for l in range(64):
-            if byte_off[l] + 16 <= nbytes:
-                out[l] = src.reshape(-1)[el[l]:el[l] + 8]
+            if voff[l] + 16 <= nbytes:
+                a = voff[l] + soff
+                assert a + 16 <= nbytes, "in-range VGPR offset + scalar offset leaves the buffer"
+                out[l] = src.reshape(-1)[a // 2:a // 2 + 8]
+            else:
+                assert voff[l] >= nbytes
         return out
 
     def land(self, base, vals):
@@ -95,7 +101,7 @@ class Block:
     def dma(self, wv, which, lds_base, voff, soff):
         if self.pass_ == "rest":
             return
-        vals = self.gload(which, voff + soff)
+        vals = self.gload(which, voff, soff)
         if self.mode == "dma_early_read_late":
             self.land(lds_base, vals)
         wv.vmq.append((lds_base, vals))
@@ -130,17 +136,17 @@ class Block:
     # ---- the kernel's helpers, same names ---------------------------------------------------------------------------
     def stage_x(self, wv, bufi, tile, h):
         rg = (wv.wave & 3) + 8 * (wv.wave >> 2) + 4 * h
-        so = tile * (BK * 2) + h * wv.x_half
+        so = tile * (BK * 2)
         dst = bufi * BUF + x_sub(0, 0) + rg * (2 * SUB)
-        self.dma(wv, 0, dst, wv.x_voff, so)
-        self.dma(wv, 0, dst + SUB, wv.x_voff, so + 64)
+        self.dma(wv, 0, dst, wv.x_voff[h], so)
+        self.dma(wv, 0, dst + SUB, wv.x_voff[h], so + 64)
 
     def stage_w(self, wv, bufi, tile, g):
         rg = 8 * g + wv.wave
-        so = tile * (BK * 2) + g * wv.w_gate
+        so = tile * (BK * 2)
         dst = bufi * BUF + w_sub(0, 0) + rg * (2 * SUB)
-        self.dma(wv, 1, dst, wv.w_voff, so)
-        self.dma(wv, 1, dst + SUB, wv.w_voff, so + 64)
+        self.dma(wv, 1, dst, wv.w_voff[g], so)
+        self.dma(wv, 1, dst + SUB, wv.w_voff[g], so + 64)
 
     def read_x(self, wv, bufi, mh):
         for mf in range(4):

@@ -98,8 +98,10 @@ __device__ __forceinline__ float gelu_as(float x) {
 
 struct Ctx {
   __amdgpu_buffer_rsrc_t xr, wr_;   // buffer descriptors: rows beyond M (or 2I) read as zeros
-  int x_voff, w_voff;               // per-lane byte offsets of the lane's 16 bytes of its wave's subtile (k tile 0, k half 0)
-  int x_half, w_gate;               // bytes from m half 0 to m half 1 (64 rows), from value rows to gate rows (I rows)
+  // per-lane byte offsets of the lane's 16 bytes of its wave's subtile (k tile 0, k half 0): [m half] / [value, gate].  Everything
+  // that selects a ROW is in these (the buffer range check -- rows beyond the tensor read as zeros -- looks at the VGPR offset; the
+  // scalar offset, which the check may ignore, only moves inside a row)
+  int x_voff[2], w_voff[2];
   int wave;                         // wave id (wave-uniform)
   int xrd, wrd;                     // per-lane LDS byte addresses of fragment (row group 0 of this wave, k half 0), buffer 0
 };
@@ -108,19 +110,19 @@ struct Ctx {
 template <int BUFI>
 __device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, int tile, int h) {
   const int rg = (c.wave & 3) + 8 * (c.wave >> 2) + 4 * h;   // rows read in phase 1 (h = 0) / phase 3 (h = 1) of either wave row
-  const int so = tile * (BK * 2) + h * c.x_half;
+  const int so = tile * (BK * 2);
   uint8_t* dst = lds + BUFI * BUF + x_sub(0, 0) + rg * (2 * SUB);
   // the instruction's immediate offset would move the LDS address as well as the memory address: the k half goes in soffset
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, c.x_voff, so, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, c.x_voff, so + 64, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, c.x_voff[h], so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, c.x_voff[h], so + 64, 0, 0);
 }
 template <int BUFI>
 __device__ __forceinline__ void stage_w(uint8_t* lds, const Ctx& c, int tile, int g) {
   const int rg = 8 * g + c.wave;                              // value row groups 0..7, gate row groups 8..15
-  const int so = tile * (BK * 2) + g * c.w_gate;
+  const int so = tile * (BK * 2);
   uint8_t* dst = lds + BUFI * BUF + w_sub(0, 0) + rg * (2 * SUB);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)dst, 16, c.w_voff, so, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)(dst + SUB), 16, c.w_voff, so + 64, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)dst, 16, c.w_voff[g], so, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)(dst + SUB), 16, c.w_voff[g], so + 64, 0, 0);
 }
 
 template <class T>
@@ -211,7 +213,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
 // EPI 1: plain projection + bias -- W is [I, K] (I = output columns), the halves are rows n0.. and n0 + 128.., out is [M, I];
 //        the same main loop, kept so that the schedule can be timed against hipBLASLt on every projection of the block
 template <class T, int EPI>
-__global__ void __launch_bounds__(512, 1)
+__global__ void __launch_bounds__(512, 2)
 k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
              uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
@@ -239,11 +241,11 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
   const int row_bytes = K * 2;
   c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * row_bytes), 0x00020000);
   c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)(EPI == 0 ? 2 : 1) * I * row_bytes), 0x00020000);
-  c.x_voff = (m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow) * row_bytes + skb;
-  c.x_half = 64 * row_bytes;
+  c.x_voff[0] = (m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow) * row_bytes + skb;
+  c.x_voff[1] = c.x_voff[0] + 64 * row_bytes;
   // LDS row (row group w, row i) of the value / gate half holds W row n0 + 32 (w >> 1) + 8 (i >> 2) + (i & 3) + 4 (w & 1)
-  c.w_voff = (n0 + 32 * (c.wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (c.wave & 1)) * row_bytes + skb;
-  c.w_gate = gap * row_bytes;
+  c.w_voff[0] = (n0 + 32 * (c.wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (c.wave & 1)) * row_bytes + skb;
+  c.w_voff[1] = c.w_voff[0] + gap * row_bytes;
   // fragment read: row lane & 15, k bytes 16 (lane >> 4), swizzled; this wave's first row group
   const int rd = swz((lane & 15) * 64 + (lane >> 4) * 16);
   c.xrd = rd + wrow * 8 * (2 * SUB);
