@@ -54,8 +54,21 @@ class Wave:
         ps = swz(16 * lane)
         srow, skb = ps >> 6, ps & 63
         rb = blk.K * 2
-        x0 = (blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow) * rb + skb
-        self.x_voff = [x0, x0 + 64 * rb]
+        xrb = rb // 9 if blk.conv else rb                   # CONV: one pixel's Cin values
+        xrow0 = blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow
+        x0 = xrow0 * xrb + skb
+        self.x_voff = [x0, x0 + 64 * xrb]
+        self.px_mask = [np.zeros(64, np.int64), np.zeros(64, np.int64)]
+        if blk.conv:
+            img_h, img_w = blk.conv
+            for h in range(2):
+                m = xrow0 + 64 * h
+                rem = m % (img_h * img_w)
+                py, px = rem // img_w, rem % img_w
+                for t in range(9):
+                    yy, xx = py + t // 3 - 1, px + t % 3 - 1
+                    ok = (m < blk.M) & (yy >= 0) & (yy < img_h) & (xx >= 0) & (xx < img_w)
+                    self.px_mask[h] |= ok.astype(np.int64) << t
         w0 = (blk.n0 + 32 * (wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (wave & 1)) * rb + skb
         self.w_voff = [w0, w0 + blk.gap * rb]
         rd = swz((lane & 15) * 64 + (lane >> 4) * 16)
@@ -68,9 +81,11 @@ class Wave:
 
 
 class Block:
-    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None, epi=0):
+    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None, epi=0, conv=None):
         self.x, self.w, self.bias, self.M, self.K, self.I, self.m0, self.n0 = x, w, bias, M, K, I, m0, n0
         self.epi, self.gap = epi, (I if epi == 0 else BN)
+        self.conv = conv                                # None, or (img_h, img_w): x is NHWC [B, img_h, img_w, K / 9]
+        self.cpt = K // (9 * BK) if conv else 1
         self.mode, self.breakage = mode, breakage
         self.lds = np.full(2 * BUF // 2, np.nan)      # 16-bit elements; NaN = never written
         self.waves = [Wave(self, i) for i in range(8)]
@@ -93,6 +108,18 @@ class Block:
             else:
                 assert voff[l] >= nbytes
         return out
+
+    def k_pos(self, tile):
+        """KPos of the .hip file, derived from the tile index (the kernel advances it incrementally: k_next)."""
+        pos = (0, 0, 0)
+        for _ in range(tile):                       # k_next of the .hip file
+            t, tap, ct = pos
+            t, ct = t + 1, ct + 1 if self.conv else ct
+            if self.conv and ct == self.cpt:
+                ct, tap = 0, tap + 1
+            pos = (t, tap, ct)
+        assert pos == ((tile, tile // self.cpt, tile % self.cpt) if self.conv else (tile, 0, 0))
+        return pos
 
     def land(self, base, vals):
         e0 = base // 2
@@ -136,8 +163,16 @@ class Block:
     # ---- the kernel's helpers, same names ---------------------------------------------------------------------------
     def stage_x(self, wv, bufi, tile, h):
         rg = (wv.wave & 3) + 8 * (wv.wave >> 2) + 4 * h
-        so = tile * (BK * 2)
         dst = bufi * BUF + x_sub(0, 0) + rg * (2 * SUB)
+        if self.conv:
+            _, tap, ct = self.k_pos(tile)
+            dy, dx = tap // 3 - 1, tap - 3 * (tap // 3) - 1
+            delta = (dy * self.conv[1] + dx) * (self.K // 9 * 2) + ct * (BK * 2)
+            vo = np.where((wv.px_mask[h] >> tap) & 1, wv.x_voff[h] + delta, 0x7ffffff0)
+            self.dma(wv, 0, dst, vo, 0)
+            self.dma(wv, 0, dst + SUB, vo, 64)
+            return
+        so = tile * (BK * 2)
         self.dma(wv, 0, dst, wv.x_voff[h], so)
         self.dma(wv, 0, dst + SUB, wv.x_voff[h], so + 64)
 
@@ -311,11 +346,12 @@ def gelu_as(x):
     return x - h if x > 0 else h
 
 
-def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0):
-    """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K])."""
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None):
+    """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K]); conv = (B, H, W): 3x3 convolution of an
+    NHWC image with Cin = K / 9 as an implicit GEMM (M = B H W)."""
     rng = np.random.default_rng(seed)
     wrows = 2 * I if epi == 0 else I
-    x = rng.integers(-4, 5, size=(M, K)).astype(np.float64)
+    x = rng.integers(-4, 5, size=(M, K // 9 if conv else K)).astype(np.float64)
     w = rng.integers(-4, 5, size=(wrows, K)).astype(np.float64)
     bias = rng.integers(-8, 9, size=wrows).astype(np.float64) / 4
     lin = np.full((M, wrows), np.nan)
@@ -333,12 +369,20 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0):
         rb, cb = first + (tid % per_group) % rows_here, (tid % per_group) // rows_here
         assert 0 <= rb < nbm and 0 <= cb < nbn
         seen.add((rb, cb))
-        blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi)
+        blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi, conv[1:] if conv else None)
         blk.flip = flip
         blk.run()
         blk.epilogue(lin, out)
     assert len(seen) == nb, "workgroup remap is not a bijection"
-    ref = x @ w.T + bias
+    if conv:
+        Bn, H, Wd = conv
+        Cin = K // 9
+        img = np.zeros((Bn, H + 2, Wd + 2, Cin))
+        img[:, 1:-1, 1:-1] = x.reshape(Bn, H, Wd, Cin)
+        cols = np.concatenate([img[:, dy:dy + H, dx:dx + Wd] for dy in range(3) for dx in range(3)], axis=-1)   # [B,H,W,9 Cin], tap-major
+        ref = cols.reshape(M, K) @ w.T + bias
+    else:
+        ref = x @ w.T + bias
     ok_lin = np.array_equal(lin, ref)
     if epi == 1:
         return ok_lin, 0.0
@@ -375,6 +419,12 @@ def main():
             for mode in ("dma_early_read_late", "dma_late_read_early"):
                 ok, _ = run_case(M, K, N, mode, epi=1)
                 print(f"linear M={M} K={K} N={N} {mode:>20s}: projection {'exact' if ok else 'WRONG'}")
+                bad += not ok
+    if not a.breakage:
+        for (Bn, H, Wd, Cin, N) in ([(2, 12, 12, 64, 128)] if a.quick else [(2, 12, 12, 64, 128), (1, 9, 20, 128, 200), (3, 8, 8, 64, 256)]):
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                ok, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd))
+                print(f"conv3x3 B={Bn} {H}x{Wd} Cin={Cin} N={N} {mode:>20s}: {'exact' if ok else 'WRONG'}")
                 bad += not ok
     if a.breakage:
         print("replay", "caught the deliberately broken schedule" if bad else "DID NOT catch the broken schedule")

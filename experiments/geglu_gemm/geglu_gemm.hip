@@ -102,19 +102,47 @@ struct Ctx {
   // that selects a ROW is in these (the buffer range check -- rows beyond the tensor read as zeros -- looks at the VGPR offset; the
   // scalar offset, which the check may ignore, only moves inside a row)
   int x_voff[2], w_voff[2];
+  int px_mask[2];                   // CONV: bit t set = tap t of the lane's pixel (m half 0 / 1) lies inside the image
+  int img_w, cin2, cpt;             // CONV: image width (pixels), bytes per pixel (2 Cin), K tiles per tap (Cin / 64)
   int wave;                         // wave id (wave-uniform)
   int xrd, wrd;                     // per-lane LDS byte addresses of fragment (row group 0 of this wave, k half 0), buffer 0
 };
 
+// position of a K tile (wave-uniform).  GEMM: k = 64 tile.  CONV (3x3, stride 1, pad 1, NHWC): K = 9 taps x Cin, tile -> (tap, 64-channel
+// block ct); the A operand row of output pixel m at tap (dy, dx) is the Cin vector of pixel m + dy W + dx, or zeros outside the image
+struct KPos {
+  int tile, tap, ct;
+};
+template <bool CONV>
+__device__ __forceinline__ KPos k_next(KPos p, int cpt) {
+  ++p.tile;
+  if (CONV) {
+    ++p.ct;
+    if (p.ct == cpt) {
+      p.ct = 0;
+      ++p.tap;
+    }
+  }
+  return p;
+}
+
 // one half tile = 16 subtiles: wave w fills row group `rg` (both k halves) -- 2 LDS-DMAs of 1 KiB
-template <int BUFI>
-__device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, int tile, int h) {
+template <int BUFI, bool CONV>
+__device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, KPos p, int h) {
   const int rg = (c.wave & 3) + 8 * (c.wave >> 2) + 4 * h;   // rows read in phase 1 (h = 0) / phase 3 (h = 1) of either wave row
-  const int so = tile * (BK * 2);
   uint8_t* dst = lds + BUFI * BUF + x_sub(0, 0) + rg * (2 * SUB);
   // the instruction's immediate offset would move the LDS address as well as the memory address: the k half goes in soffset
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, c.x_voff[h], so, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, c.x_voff[h], so + 64, 0, 0);
+  if (CONV) {
+    const int dy = p.tap / 3 - 1, dx = p.tap - 3 * (p.tap / 3) - 1;              // scalar
+    const int delta = (dy * c.img_w + dx) * c.cin2 + p.ct * (BK * 2);             // scalar, may be negative
+    const int vo = ((c.px_mask[h] >> p.tap) & 1) ? c.x_voff[h] + delta : 0x7ffffff0;   // outside the image: out of range = zeros
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, vo, 64, 0, 0);
+  } else {
+    const int so = p.tile * (BK * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, c.x_voff[h], so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, c.x_voff[h], so + 64, 0, 0);
+  }
 }
 template <int BUFI>
 __device__ __forceinline__ void stage_w(uint8_t* lds, const Ctx& c, int tile, int g) {
@@ -165,16 +193,16 @@ __device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const Frags<T>& f) {
   __builtin_amdgcn_s_setprio(0);
 }
 
-// the four phases of K tile `tile` (buffer BUFI).  s1: tile + 1 exists, s2: tile + 2 exists (wave-uniform).
-template <class T, int BUFI>
+// the four phases of K tile `tile` (buffer BUFI).  s1: tile + 1 exists, s2: tile + 2 exists (wave-uniform); p1 / p2 their positions.
+template <class T, int BUFI, bool CONV>
 __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1,
-                                            bool s2) {
+                                            bool s2, KPos p1, KPos p2) {
   // ---- phase 1: m half 0 x value.  12 fragment reads: the 4 W reads first, so that lgkmcnt(8) retires them before the
   // barrier and the value half of this buffer may be re-staged one phase from now.
   read_w<T, BUFI, 0>(lds, c, f);
   __builtin_amdgcn_sched_barrier(0);
   read_x<T, BUFI>(lds, c, f, 0);
-  if (s1) stage_x<BUFI ^ 1>(lds, c, tile + 1, 1);       // x m-half 1 of tile + 1: its buffer's copy was last read 2 phases ago
+  if (s1) stage_x<BUFI ^ 1, CONV>(lds, c, p1, 1);       // x m-half 1 of tile + 1: its buffer's copy was last read 2 phases ago
   ED_WAIT_LGKM(8);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
@@ -191,7 +219,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   ED_BARRIER();
   // ---- phase 3: m half 1 x gate
   read_x<T, BUFI>(lds, c, f, 1);
-  if (s2) stage_x<BUFI>(lds, c, tile + 2, 0);           // x m-half 0 of tile + 2 (read in phase 1)
+  if (s2) stage_x<BUFI, CONV>(lds, c, p2, 0);           // x m-half 0 of tile + 2 (read in phase 1)
   ED_BARRIER();
   ED_WAIT_LGKM(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -212,10 +240,13 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
 // EPI 0: GEGLU -- W is [2 I, K], the two 128-row halves of the tile are value rows n0.. and gate rows I + n0.., out is [M, I]
 // EPI 1: plain projection + bias -- W is [I, K] (I = output columns), the halves are rows n0.. and n0 + 128.., out is [M, I];
 //        the same main loop, kept so that the schedule can be timed against hipBLASLt on every projection of the block
-template <class T, int EPI>
+// CONV (with EPI 1): x is an NHWC image [B, img_h, img_w, Cin], W is [I, 3, 3, Cin] (a torch Conv2d weight in channels_last memory
+//        format), K = 9 Cin, M = B img_h img_w, out is NHWC [M, I]: 3x3, stride 1, zero padding 1 as an implicit GEMM -- only the
+//        addresses of the A operand differ (stage_x)
+template <class T, int EPI, bool CONV>
 __global__ void __launch_bounds__(512, 2)
 k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-             uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks) {
+             uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
 
   // workgroup -> (row block, column block).  Id b runs on XCD b % 8: give every XCD a contiguous run of tile ids, and walk
@@ -238,11 +269,33 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
 
   // a lane's 16 bytes of a subtile: position 16 lane, element (row, k byte) after the swizzle
   const int ps = swz(16 * lane), srow = ps >> 6, skb = ps & 63;
-  const int row_bytes = K * 2;
-  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * row_bytes), 0x00020000);
+  const int row_bytes = K * 2;                                   // a W row; for a GEMM also an x row
+  const int x_row_bytes = CONV ? row_bytes / 9 : row_bytes;      // CONV: one pixel's Cin values
+  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * x_row_bytes), 0x00020000);
   c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)(EPI == 0 ? 2 : 1) * I * row_bytes), 0x00020000);
-  c.x_voff[0] = (m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow) * row_bytes + skb;
-  c.x_voff[1] = c.x_voff[0] + 64 * row_bytes;
+  const int xrow0 = m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow;   // the lane's row of m half 0; m half 1 is 64 rows on
+  c.x_voff[0] = xrow0 * x_row_bytes + skb;
+  c.x_voff[1] = c.x_voff[0] + 64 * x_row_bytes;
+  c.img_w = img_w;
+  c.cin2 = x_row_bytes;
+  c.cpt = CONV ? K / (9 * BK) : 1;
+  c.px_mask[0] = c.px_mask[1] = 0;
+  if (CONV) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = xrow0 + 64 * h;
+      if (m < M) {
+        const int rem = m % (img_h * img_w), py = rem / img_w, px = rem - py * img_w;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+          if (yy >= 0 && yy < img_h && xx >= 0 && xx < img_w) mask |= 1 << t;
+        }
+        c.px_mask[h] = mask;
+      }
+    }
+  }
   // LDS row (row group w, row i) of the value / gate half holds W row n0 + 32 (w >> 1) + 8 (i >> 2) + (i & 3) + 4 (w & 1)
   c.w_voff[0] = (n0 + 32 * (c.wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (c.wave & 1)) * row_bytes + skb;
   c.w_voff[1] = c.w_voff[0] + gap * row_bytes;
@@ -279,13 +332,16 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
 
   const int nt = K / BK;
   // prologue: all of tile 0, then the three half tiles of tile 1 the loop does not stage itself
+  const KPos p0 = {0, 0, 0};
+  KPos pa = k_next<CONV>(p0, c.cpt);      // position of tile t + 1
+  KPos pb = k_next<CONV>(pa, c.cpt);      // position of tile t + 2
   stage_w<0>(lds, c, 0, 0);
-  stage_x<0>(lds, c, 0, 0);
+  stage_x<0, CONV>(lds, c, p0, 0);
   stage_w<0>(lds, c, 0, 1);
-  stage_x<0>(lds, c, 0, 1);
+  stage_x<0, CONV>(lds, c, p0, 1);
   if (nt > 1) {
     stage_w<1>(lds, c, 1, 0);
-    stage_x<1>(lds, c, 1, 0);
+    stage_x<1, CONV>(lds, c, pa, 0);
     stage_w<1>(lds, c, 1, 1);
     ED_WAIT_VM(6);
   } else {
@@ -296,10 +352,14 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
 
   int t = 0;
   for (; t + 1 < nt; t += 2) {
-    tile_phases<T, 0>(lds, c, f, acc, t, true, t + 2 < nt);
-    tile_phases<T, 1>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt);
+    tile_phases<T, 0, CONV>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
+    pa = pb;
+    pb = k_next<CONV>(pb, c.cpt);
+    tile_phases<T, 1, CONV>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt, pa, pb);
+    pa = pb;
+    pb = k_next<CONV>(pb, c.cpt);
   }
-  if (t < nt) tile_phases<T, 0>(lds, c, f, acc, t, false, false);
+  if (t < nt) tile_phases<T, 0, CONV>(lds, c, f, acc, t, false, false, pa, pb);
   if (wrow == 0) ED_BARRIER();    // pair the extra barrier of the second wave row
 
   // epilogue: one 16-byte store per (lane, 16-row block): 8 consecutive columns of one row
@@ -340,31 +400,38 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
 // dtype: 1 = bf16, 2 = f16 (the library's ED_BF16 / ED_F16 codes).  Returns 0, a hipError_t, or -1 for unsupported shapes.
 //   ed_exp_geglu_gemm: out[M, I] = (x W_v^T + b_v) * gelu(x W_g^T + b_g),   W [2 I, K], I % 128 == 0
 //   ed_exp_linear:     out[M, N] = x W^T + b,                                W [N, K],   N % 8 == 0
-template <int EPI>
-static int launch(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I, void* stream) {
+//   ed_exp_conv3x3:    out[B,H,W,N] = conv3x3(x[B,H,W,Cin], W[N,3,3,Cin]) + b, stride 1, padding 1, NHWC;  Cin % 64 == 0, N % 8 == 0
+template <int EPI, bool CONV>
+static int launch(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I, int img_h, int img_w,
+                  void* stream) {
   if (M == 0) return 0;
   if (K % BK != 0 || K < BK || (EPI == 0 ? I % BN != 0 : I % 8 != 0)) return -1;
-  if (M * (int64_t)K * 2 >= (1ll << 31) || (int64_t)2 * I * K * 2 >= (1ll << 31)) return -1;   // 32-bit buffer offsets
+  if (CONV && (K % (9 * BK) != 0 || img_h <= 0 || img_w <= 0 || M % ((int64_t)img_h * img_w) != 0)) return -1;
+  if (M * (int64_t)(CONV ? K / 9 : K) * 2 >= 0x7ffffff0ll || (int64_t)2 * I * K * 2 >= (1ll << 31)) return -1;   // 32-bit buffer offsets
   if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15u)) return -1;
   const int nbn = EPI == 0 ? I / BN : (I + 2 * BN - 1) / (2 * BN);
   const int64_t nb = ((M + BM - 1) / BM) * nbn;
   if (nb >= (1ll << 31)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == 1)
-    k_geglu_gemm<BF, EPI><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out,
-                                                 (int)M, K, I, nbn, (int)nb);
+    k_geglu_gemm<BF, EPI, CONV><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,
+                                                       (uint16_t*)out, (int)M, K, I, nbn, (int)nb, img_h, img_w);
   else if (dtype == 2)
-    k_geglu_gemm<HF, EPI><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out,
-                                                 (int)M, K, I, nbn, (int)nb);
+    k_geglu_gemm<HF, EPI, CONV><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,
+                                                       (uint16_t*)out, (int)M, K, I, nbn, (int)nb, img_h, img_w);
   else
     return -1;
   return (int)hipGetLastError();
 }
 extern "C" int ed_exp_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I,
                                  void* stream) {
-  return launch<0>(x, w, bias, out, dtype, M, K, I, stream);
+  return launch<0, false>(x, w, bias, out, dtype, M, K, I, 0, 0, stream);
 }
 extern "C" int ed_exp_linear(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int N,
                              void* stream) {
-  return launch<1>(x, w, bias, out, dtype, M, K, N, stream);
+  return launch<1, false>(x, w, bias, out, dtype, M, K, N, 0, 0, stream);
+}
+extern "C" int ed_exp_conv3x3(const void* x, const void* w, const void* bias, void* out, int dtype, int B, int H, int W, int Cin,
+                              int N, void* stream) {
+  return launch<1, true>(x, w, bias, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, stream);
 }

@@ -31,6 +31,8 @@ def build():
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", src, "-o", so])
     lib = ctypes.CDLL(so)
+    lib.ed_exp_conv3x3.restype = ctypes.c_int
+    lib.ed_exp_conv3x3.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
     for fn in (lib.ed_exp_geglu_gemm, lib.ed_exp_linear):
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -164,6 +166,44 @@ def main():
             rec.update({"this_ms_median": med(tm), "hipblaslt_ms_median": med(tl), "this_tflops": flops / med(tm) / 1e9,
                         "hipblaslt_tflops": flops / med(tl) / 1e9})
         report["linear"].append(rec)
+        print(json.dumps(rec), flush=True)
+    # the same main loop as a 3x3 convolution (implicit GEMM over an NHWC image) on the UNet's convolution shapes at batch 20:
+    # MIOpen's CK kernels run these at ~840 TFLOP/s in fp16 (19.7 % of GPU time)
+    report["conv3x3"] = []
+    import torch.nn.functional as F
+    for (B, H, W, Cin, N) in [(2, 12, 20, 64, 200), (20, 32, 32, 1280, 1280), (20, 128, 128, 320, 320), (20, 64, 64, 640, 640),
+                              (20, 32, 32, 2560, 1280), (20, 64, 64, 1920, 640), (6, 32, 32, 1280, 1280)]:
+        x = (torch.rand(B, Cin, H, W, generator=g) * 2 - 1).to(dev, dt).contiguous(memory_format=torch.channels_last)
+        w = ((torch.rand(N, Cin, 3, 3, generator=g) * 2 - 1) / (9 * Cin) ** 0.5).to(dev, dt).contiguous(memory_format=torch.channels_last)
+        b = (torch.rand(N, generator=g) * 2 - 1).to(dev, dt)
+        out = torch.empty(B, N, H, W, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+        code = 1 if dt == torch.bfloat16 else 2
+
+        def mine():
+            rc = lib.ed_exp_conv3x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), code, B, H, W, Cin, N,
+                                    torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"ed_exp_conv3x3 returned {rc}")
+            return out
+
+        mine()
+        nb = min(B, 2)
+        ref = F.conv2d(x[:nb].float(), w.float(), b.float(), padding=1)
+        err = ((out[:nb].float() - ref).norm() / ref.norm()).item()
+        first = out.clone()
+        identical = all(bool(torch.equal(mine(), first)) for _ in range(10))
+        ok = err < 1e-3 * (8 if dt == torch.bfloat16 else 1) and identical
+        ok_all &= ok
+        rec = {"B": B, "H": H, "W": W, "Cin": Cin, "N": N, "rel_l2_vs_fp32": err, "bit_identical_10_launches": identical, "ok": ok}
+        if B * H * W >= 4096:
+            tm, tl = [], []
+            for _ in range(a.rounds):
+                tm.append(timed(mine))
+                tl.append(timed(lambda: F.conv2d(x, w, b, padding=1)))
+            flops = 2.0 * B * H * W * 9 * Cin * N
+            rec.update({"this_ms_median": med(tm), "miopen_ms_median": med(tl), "this_tflops": flops / med(tm) / 1e9,
+                        "miopen_tflops": flops / med(tl) / 1e9})
+        report["conv3x3"].append(rec)
         print(json.dumps(rec), flush=True)
     report["ok"] = ok_all
     if a.out:
