@@ -75,6 +75,24 @@ def med(v):
     return sorted(v)[len(v) // 2]
 
 
+def diagnose(got, ref, tol, label):
+    """Where is it wrong?  Error map over 16-row x 8-column cells (the kernel's store granule): which row blocks of the 256-row
+    tile, which wave columns -- enough to tell an index bug (a regular pattern) from a race (scattered, changes between runs)."""
+    bad = ((got - ref).abs() > tol * (1 + ref.abs())) | ~torch.isfinite(got)
+    M, N = bad.shape
+    Mp, Np = (M + 15) // 16 * 16, (N + 7) // 8 * 8
+    pad = torch.zeros(Mp, Np, dtype=torch.bool, device=bad.device)
+    pad[:M, :N] = bad
+    cells = pad.view(Mp // 16, 16, Np // 8, 8).any(3).any(1)
+    idx = cells.nonzero()[:24].tolist()
+    print(f"  [{label}] wrong elements {int(bad.sum())} / {bad.numel()}, NaN/inf {int((~torch.isfinite(got)).sum())}, exact zeros "
+          f"{int((got == 0).sum())}; wrong 16x8 cells {int(cells.sum())} / {cells.numel()}; first (row16, col8): {idx}")
+    rows = cells.any(1).nonzero().flatten()
+    cols = cells.any(0).nonzero().flatten()
+    print(f"  [{label}] row16 blocks mod 16 (position in the 256-row tile): {sorted(set((rows % 16).tolist()))}; "
+          f"col8 groups mod 16 (position in a 128-column half): {sorted(set((cols % 16).tolist()))}")
+
+
 def reference_fp32(x, w, b):
     y = x.float() @ w.float().t() + (b.float() if b is not None else 0)
     h, g = y.chunk(2, -1)
@@ -92,7 +110,7 @@ def main():
     lib = build()
     from elasticdiffusion_official_amd import ops   # the path being replaced: hipBLASLt linear + ed_geglu
 
-    shapes = [(300, 192, 256), (256, 64, 128), (1000, 320, 1280), (81920, 640, 2560), (20480, 1280, 5120), (24576, 640, 2560),
+    shapes = [(256, 64, 128), (256, 128, 128), (300, 192, 256), (1000, 320, 1280), (81920, 640, 2560), (20480, 1280, 5120), (24576, 640, 2560),
               (6144, 1280, 5120)]
     g = torch.Generator(device="cpu").manual_seed(0)
     report = {"dtype": a.dtype, "shapes": []}
@@ -118,6 +136,8 @@ def main():
             identical &= bool(torch.equal(out, first))
         ok = err < 2e-3 * (4 if dt == torch.bfloat16 else 1) and identical and bool(torch.isfinite(out).all())
         ok_all &= ok
+        if not ok:
+            diagnose(first[rows].float(), ref, 0.02 if dt == torch.bfloat16 else 0.005, f"geglu M={M} K={K} I={I}")
         rec = {"M": M, "K": K, "I": I, "rel_l2_vs_fp32": err, "rel_l2_unfused_vs_fp32": err_unfused, "max_abs": maxabs,
                "bit_identical_20_launches": identical, "ok": ok}
         if M >= 4096:   # timing A/B
@@ -141,7 +161,7 @@ def main():
     # the same main loop as a plain projection (out = x W^T + b) on the transformer blocks' other GEMM shapes at batch 20 / 6:
     # is the schedule itself faster or slower than the hipBLASLt kernels the UNet uses today (43 % of GPU time)?
     report["linear"] = []
-    for (M, K, N) in [(300, 128, 200), (81920, 640, 1920), (81920, 640, 640), (81920, 2560, 640), (20480, 1280, 3840),
+    for (M, K, N) in [(256, 64, 256), (300, 128, 200), (81920, 640, 1920), (81920, 640, 640), (81920, 2560, 640), (20480, 1280, 3840),
                       (20480, 1280, 1280), (20480, 5120, 1280), (1540, 2048, 1280), (24576, 640, 1920), (6144, 1280, 3840)]:
         x = (torch.rand(M, K, generator=g) * 2 - 1).to(dev, dt)
         w = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(dev, dt)
@@ -155,6 +175,8 @@ def main():
         identical = all(bool(torch.equal(linear(lib, x, w, b, out.zero_()), first)) for _ in range(10))
         ok = err < 1e-3 * (8 if dt == torch.bfloat16 else 1) and identical
         ok_all &= ok
+        if not ok:
+            diagnose(first[rows].float(), ref, 0.02 if dt == torch.bfloat16 else 0.005, f"linear M={M} K={K} N={N}")
         rec = {"M": M, "K": K, "N": N, "rel_l2_vs_fp32": err, "bit_identical_10_launches": identical, "ok": ok}
         if M >= 1024:
             y = torch.empty(M, N, device=dev, dtype=dt)
