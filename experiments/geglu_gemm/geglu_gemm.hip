@@ -35,6 +35,7 @@
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC geglu_gemm.hip -o libgeglu_gemm.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -194,7 +195,9 @@ __device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const Frags<T>& f) {
 }
 
 // the four phases of K tile `tile` (buffer BUFI).  s1: tile + 1 exists, s2: tile + 2 exists (wave-uniform); p1 / p2 their positions.
-template <class T, int BUFI, bool CONV>
+// SAFE (diagnosis build, `ED_EXP_SAFE=1`): every DMA is drained in the barrier interval that issued it -- slow, and the schedule's
+// counted waits play no part: if SAFE is right and the normal build is not, the counted waits are at fault, not the addresses.
+template <class T, int BUFI, bool CONV, bool SAFE>
 __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1,
                                             bool s2, KPos p1, KPos p2) {
   // ---- phase 1: m half 0 x value.  12 fragment reads: the 4 W reads first, so that lgkmcnt(8) retires them before the
@@ -204,6 +207,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   read_x<T, BUFI>(lds, c, f, 0);
   if (s1) stage_x<BUFI ^ 1, CONV>(lds, c, p1, 1);       // x m-half 1 of tile + 1: its buffer's copy was last read 2 phases ago
   ED_WAIT_LGKM(8);
+  if (SAFE) ED_WAIT_VM(0);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -212,6 +216,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   // ---- phase 2: m half 0 x gate
   read_w<T, BUFI, 1>(lds, c, f);
   if (s2) stage_w<BUFI>(lds, c, tile + 2, 0);           // value rows of tile + 2 (read in phase 1, retired before its barrier)
+  if (SAFE) ED_WAIT_VM(0);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -220,6 +225,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   // ---- phase 3: m half 1 x gate
   read_x<T, BUFI>(lds, c, f, 1);
   if (s2) stage_x<BUFI, CONV>(lds, c, p2, 0);           // x m-half 0 of tile + 2 (read in phase 1)
+  if (SAFE) ED_WAIT_VM(0);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -228,7 +234,8 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   // ---- phase 4: m half 1 x value (fragments already in registers)
   if (s2) {
     stage_w<BUFI>(lds, c, tile + 2, 1);                 // gate rows of tile + 2 (read in phase 2)
-    ED_WAIT_VM(6);                                      // all of tile + 1 has landed; 3 half tiles of tile + 2 stay in flight
+    if (SAFE) ED_WAIT_VM(0);
+    else ED_WAIT_VM(6);                                 // all of tile + 1 has landed; 3 half tiles of tile + 2 stay in flight
   } else {
     ED_WAIT_VM(0);                                      // last two tiles: nothing newer to leave in flight
   }
@@ -243,7 +250,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
 // CONV (with EPI 1): x is an NHWC image [B, img_h, img_w, Cin], W is [I, 3, 3, Cin] (a torch Conv2d weight in channels_last memory
 //        format), K = 9 Cin, M = B img_h img_w, out is NHWC [M, I]: 3x3, stride 1, zero padding 1 as an implicit GEMM -- only the
 //        addresses of the A operand differ (stage_x)
-template <class T, int EPI, bool CONV>
+template <class T, int EPI, bool CONV, bool SAFE>
 __global__ void __launch_bounds__(512, 2)
 k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
              uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w) {
@@ -343,7 +350,8 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
     stage_w<1>(lds, c, 1, 0);
     stage_x<1, CONV>(lds, c, pa, 0);
     stage_w<1>(lds, c, 1, 1);
-    ED_WAIT_VM(6);
+    if (SAFE) ED_WAIT_VM(0);
+    else ED_WAIT_VM(6);
   } else {
     ED_WAIT_VM(0);
   }
@@ -352,14 +360,14 @@ k_geglu_gemm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
 
   int t = 0;
   for (; t + 1 < nt; t += 2) {
-    tile_phases<T, 0, CONV>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
+    tile_phases<T, 0, CONV, SAFE>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
     pa = pb;
     pb = k_next<CONV>(pb, c.cpt);
-    tile_phases<T, 1, CONV>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt, pa, pb);
+    tile_phases<T, 1, CONV, SAFE>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt, pa, pb);
     pa = pb;
     pb = k_next<CONV>(pb, c.cpt);
   }
-  if (t < nt) tile_phases<T, 0, CONV>(lds, c, f, acc, t, false, false, pa, pb);
+  if (t < nt) tile_phases<T, 0, CONV, SAFE>(lds, c, f, acc, t, false, false, pa, pb);
   if (wrow == 0) ED_BARRIER();    // pair the extra barrier of the second wave row
 
   // epilogue: one 16-byte store per (lane, 16-row block): 8 consecutive columns of one row
@@ -413,14 +421,19 @@ static int launch(const void* x, const void* w, const void* bias, void* out, int
   const int64_t nb = ((M + BM - 1) / BM) * nbn;
   if (nb >= (1ll << 31)) return -1;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == 1)
-    k_geglu_gemm<BF, EPI, CONV><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,
-                                                       (uint16_t*)out, (int)M, K, I, nbn, (int)nb, img_h, img_w);
-  else if (dtype == 2)
-    k_geglu_gemm<HF, EPI, CONV><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,
-                                                       (uint16_t*)out, (int)M, K, I, nbn, (int)nb, img_h, img_w);
-  else
+  const char* e = getenv("ED_EXP_SAFE");
+  const bool safe = e && e[0] == '1';
+#define ED_LAUNCH(TT, SF)                                                                                                         \
+  k_geglu_gemm<TT, EPI, CONV, SF><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,          \
+                                                         (uint16_t*)out, (int)M, K, I, nbn, (int)nb, img_h, img_w)
+  if (dtype == 1) {
+    if (safe) ED_LAUNCH(BF, true); else ED_LAUNCH(BF, false);
+  } else if (dtype == 2) {
+    if (safe) ED_LAUNCH(HF, true); else ED_LAUNCH(HF, false);
+  } else {
     return -1;
+  }
+#undef ED_LAUNCH
   return (int)hipGetLastError();
 }
 extern "C" int ed_exp_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I,

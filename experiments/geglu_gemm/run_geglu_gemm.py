@@ -7,7 +7,8 @@
    [-1, 1) data -- asymmetric by construction, so a transposed operand or store cannot pass -- on a ragged small shape, a
    one-tile K, an odd tile count and the two SDXL shapes (M = 81 920, K = 640, I = 2560; M = 20 480, K = 1280, I = 5120);
 3. race screen: 20 launches per shape must be bit-identical (the kernel has no atomics and no split-K: any difference
-   between two launches is an LDS race);
+   between two launches is an LDS race); a failing shape prints an error map over the kernel's 16 x 8 store cells and is re-run
+   with the `ED_EXP_SAFE=1` build (every DMA drained in the interval that issued it) to tell an address bug from a wait bug;
 4. timing, interleaved rounds in one process (median and min): this kernel vs the path it would replace
    (F.linear through hipBLASLt + ed_geglu from libelastic_hip.so), same random data.
 The bar from VERDICT r2 item 4: not slower than hipBLASLt + ed_geglu on the two SDXL shapes.
@@ -138,6 +139,15 @@ def main():
         ok_all &= ok
         if not ok:
             diagnose(first[rows].float(), ref, 0.02 if dt == torch.bfloat16 else 0.005, f"geglu M={M} K={K} I={I}")
+            os.environ["ED_EXP_SAFE"] = "1"          # the diagnosis build: every DMA drained where it was issued
+            try:
+                safe = fused(lib, x, w, b, torch.empty_like(out))
+                torch.cuda.synchronize()
+                e2 = ((safe[rows].float() - ref).norm() / ref.norm()).item()
+                print(f"  [geglu M={M} K={K} I={I}] ED_EXP_SAFE=1 build: rel L2 {e2:.3e} -> "
+                      f"{'addresses are right, the counted waits are at fault' if e2 < 2e-2 else 'wrong as well: addresses / layout'}")
+            finally:
+                os.environ.pop("ED_EXP_SAFE", None)
         rec = {"M": M, "K": K, "I": I, "rel_l2_vs_fp32": err, "rel_l2_unfused_vs_fp32": err_unfused, "max_abs": maxabs,
                "bit_identical_20_launches": identical, "ok": ok}
         if M >= 4096:   # timing A/B
