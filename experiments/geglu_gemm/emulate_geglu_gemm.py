@@ -93,10 +93,9 @@ class Block:
 
     # ---- memory side ----------------------------------------------------------------------------------------------
     def gload(self, which, voff, soff):
-        """16 bytes per lane from x (which = 0) or W (1) through a raw buffer.  The range check (zeros when out of range) is modelled
-        on the VGPR offset alone -- the scalar offset may or may not take part in the hardware's check, so the kernel must be
-        right either way: an in-range VGPR offset must give an in-range address (asserted), an out-of-range row must already be
-        out of range by its VGPR offset."""
+        """16 bytes per lane from x (which = 0) or W (1) through a raw buffer: out-of-range offsets read as zeros.  The kernel keeps the
+        scalar and immediate offsets at 0 (soff is always 0 here); the model still range-checks the VGPR offset alone and asserts
+        that an in-range one gives an in-range address."""
         src = self.x if which == 0 else self.w
         nbytes = src.size * 2
         out = np.zeros((64, 8))
@@ -168,20 +167,20 @@ class Block:
             _, tap, ct = self.k_pos(tile)
             dy, dx = tap // 3 - 1, tap - 3 * (tap // 3) - 1
             delta = (dy * self.conv[1] + dx) * (self.K // 9 * 2) + ct * (BK * 2)
-            vo = np.where((wv.px_mask[h] >> tap) & 1, wv.x_voff[h] + delta, 0x7ffffff0)
+            vo = np.where((wv.px_mask[h] >> tap) & 1, wv.x_voff[h] + delta, 0x80000000)
             self.dma(wv, 0, dst, vo, 0)
-            self.dma(wv, 0, dst + SUB, vo, 64)
+            self.dma(wv, 0, dst + SUB, vo + 64, 0)
             return
-        so = tile * (BK * 2)
-        self.dma(wv, 0, dst, wv.x_voff[h], so)
-        self.dma(wv, 0, dst + SUB, wv.x_voff[h], so + 64)
+        vo = wv.x_voff[h] + tile * (BK * 2)
+        self.dma(wv, 0, dst, vo, 0)
+        self.dma(wv, 0, dst + SUB, vo + 64, 0)
 
     def stage_w(self, wv, bufi, tile, g):
         rg = 8 * g + wv.wave
-        so = tile * (BK * 2)
+        vo = wv.w_voff[g] + tile * (BK * 2)
         dst = bufi * BUF + w_sub(0, 0) + rg * (2 * SUB)
-        self.dma(wv, 1, dst, wv.w_voff[g], so)
-        self.dma(wv, 1, dst + SUB, wv.w_voff[g], so + 64)
+        self.dma(wv, 1, dst, vo, 0)
+        self.dma(wv, 1, dst + SUB, vo + 64, 0)
 
     def read_x(self, wv, bufi, mh):
         for mf in range(4):

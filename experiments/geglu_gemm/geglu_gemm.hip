@@ -99,9 +99,8 @@ __device__ __forceinline__ float gelu_as(float x) {
 
 struct Ctx {
   __amdgpu_buffer_rsrc_t xr, wr_;   // buffer descriptors: rows beyond M (or 2I) read as zeros
-  // per-lane byte offsets of the lane's 16 bytes of its wave's subtile (k tile 0, k half 0): [m half] / [value, gate].  Everything
-  // that selects a ROW is in these (the buffer range check -- rows beyond the tensor read as zeros -- looks at the VGPR offset; the
-  // scalar offset, which the check may ignore, only moves inside a row)
+  // per-lane byte offsets of the lane's 16 bytes of its wave's subtile (k tile 0, k half 0): [m half] / [value, gate]; the K tile
+  // and k half are added per DMA (rows beyond the tensor are beyond the buffer's range and read as zeros)
   int x_voff[2], w_voff[2];
   int px_mask[2];                   // CONV: bit t set = tap t of the lane's pixel (m half 0 / 1) lies inside the image
   int img_w, cin2, cpt;             // CONV: image width (pixels), bytes per pixel (2 Cin), K tiles per tap (Cin / 64)
@@ -132,26 +131,27 @@ template <int BUFI, bool CONV>
 __device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, KPos p, int h) {
   const int rg = (c.wave & 3) + 8 * (c.wave >> 2) + 4 * h;   // rows read in phase 1 (h = 0) / phase 3 (h = 1) of either wave row
   uint8_t* dst = lds + BUFI * BUF + x_sub(0, 0) + rg * (2 * SUB);
-  // the instruction's immediate offset would move the LDS address as well as the memory address: the k half goes in soffset
+  // LDS-DMA with everything in the VGPR offset: immediate and scalar offsets stay 0 (the immediate also moves the LDS address;
+  // composable_kernel's ck_tile forces the scalar offset to 0 for these loads on gfx950 -- amd_async_buffer_load)
   if (CONV) {
     const int dy = p.tap / 3 - 1, dx = p.tap - 3 * (p.tap / 3) - 1;              // scalar
     const int delta = (dy * c.img_w + dx) * c.cin2 + p.ct * (BK * 2);             // scalar, may be negative
-    const int vo = ((c.px_mask[h] >> p.tap) & 1) ? c.x_voff[h] + delta : 0x7ffffff0;   // outside the image: out of range = zeros
+    const int vo = ((c.px_mask[h] >> p.tap) & 1) ? c.x_voff[h] + delta : (int)0x80000000;   // outside the image: out of range = zeros
     __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, vo, 64, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, vo + 64, 0, 0, 0);
   } else {
-    const int so = p.tile * (BK * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, c.x_voff[h], so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, c.x_voff[h], so + 64, 0, 0);
+    const int vo = c.x_voff[h] + p.tile * (BK * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, vo + 64, 0, 0, 0);
   }
 }
 template <int BUFI>
 __device__ __forceinline__ void stage_w(uint8_t* lds, const Ctx& c, int tile, int g) {
   const int rg = 8 * g + c.wave;                              // value row groups 0..7, gate row groups 8..15
-  const int so = tile * (BK * 2);
+  const int vo = c.w_voff[g] + tile * (BK * 2);
   uint8_t* dst = lds + BUFI * BUF + w_sub(0, 0) + rg * (2 * SUB);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)dst, 16, c.w_voff[g], so, 0, 0);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)(dst + SUB), 16, c.w_voff[g], so + 64, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)(dst + SUB), 16, vo + 64, 0, 0, 0);
 }
 
 template <class T>
