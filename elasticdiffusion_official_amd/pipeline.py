@@ -318,6 +318,19 @@ class ElasticDiffusion(nn.Module):
         P.sampler = host_rng.PickSampler(P.pick.N)
         return P
 
+    def _strip_chunk(self, Hs, Ws, T):
+        """Timesteps per pad-strip VAE call: ~16 MiB of fp32 pixels, at most STRIP_CHUNK."""
+        s = self.vae_scale_factor
+        return max(1, min(T, STRIP_CHUNK, (16 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
+
+    def strip_pools(self, pad, T):
+        """-> {(Hs, Ws, chunk): [strip indices]}: the strips of one PadPlan whose encodes share a call shape.  Each pool is
+        ONE sharded unit list, i.e. one ``sharder.run`` (one exchange when sharded) per pool and image."""
+        pools = {}
+        for k, (dim, side_id, Hs, Ws, y0, x0) in enumerate(pad.strips):
+            pools.setdefault((Hs, Ws, self._strip_chunk(Hs, Ws, T)), []).append(k)
+        return pools
+
     @torch.no_grad()
     def _strip_frames(self, pad, timesteps, C):
         """All noised-background frames [T,C,PH,PW] of one PadPlan (ED:327-391), computed once per image instead of
@@ -346,16 +359,14 @@ class ElasticDiffusion(nn.Module):
             # per process), which is what round 2's per-rank timestep split (25 -> 21+4 / 13,12 / 7,6 per call) would have
             # paid on the first real multi-GPU run.  ~16 MiB of fp32 pixels per call, at most STRIP_CHUNK timesteps so that a 50-step
             # schedule still splits into >= 10 units for 8 ranks.
-            chunk = max(1, min(T, STRIP_CHUNK, (16 << 20) // max(1, 3 * Hs * s * Ws * s * 4)))
+            chunk = self._strip_chunk(Hs, Ws, T)
             plans.append((Hs, Ws, y0, x0, chunk, torch.cat([dr[0] for dr in draws]), torch.cat([dr[1] for dr in draws]),
                           torch.cat([dr[2] for dr in draws])))
         coef = coef_host.to(dev)
         # Strips of the same size (the two strips of a padded axis, unless the pad is odd) form ONE pool of units: 2 x 10
         # units on 8 ranks split 3,3,3,3,2,2,2,2 instead of 2 x (2,2,1,1,1,1,1,1) -- 15 % of the encodes on the busiest rank
         # instead of 20 % -- and one exchange per pool instead of one per strip.
-        pools = {}
-        for k, (Hs, Ws, y0, x0, chunk, colour, post, fwd) in enumerate(plans):
-            pools.setdefault((Hs, Ws, chunk), []).append(k)
+        pools = self.strip_pools(pad, T)
         for (Hs, Ws, chunk), members in pools.items():
             n_units = -(-T // chunk)
             # draws of the pool's strips back to back: row p*T + t = strip p of the pool at timestep index t

@@ -153,8 +153,17 @@ def _rccl_worker(port, ret):
                 pipe.seed_everything(c["seed"])
                 imgs, _ = pipe.generate_image("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
                                               resampling_steps=c["R"], output_type="pt", progress=lambda it: it, **R.LOOP_KW)
+                # what the exchange count must be: one per model forward + one per pool of same-shape pad strips
+                from elasticdiffusion_official_amd import geometry
+                h, w = pipe.get_downsample_size(c["H"], c["W"])
+                s, vc = pipe.vae_scale_factor, pipe.view_config
+                vp = geometry.ViewPlan(c["H"] // s, c["W"] // s, vc["window_size"], vc["stride"], vc["context_size"])
+                gpad, vpad = geometry.PadPlan(h, w, pipe.model_size), geometry.PadPlan(vp.Sh, vp.Sw, pipe.model_size)
+                per_phase = 1 if (gpad.PH, gpad.PW) == (vpad.PH, vpad.PW) else 2
+                phases = 2 * c["steps"] - 1 if c["R"] > 0 else c["steps"]   # RePaint phase on every step but the last
+                n_pools = sum(len(pipe.strip_pools(p, c["steps"])) for p in (gpad, vpad) if p.padded)
                 outs[(kind, forced)] = (pipe.last_latents.cpu().numpy(), pipe.sharder.exchanges, pipe._runner.stats(),
-                                        bool(torch.isfinite(imgs).all()))
+                                        bool(torch.isfinite(imgs).all()), phases * per_phase + n_pools)
         ret["ranks_seen"] = int(ones.item())
         ret["backend"] = dist.get_backend()
         ret["outs"] = outs
@@ -178,10 +187,11 @@ def test_rccl_world_size_one_exchange_path():
     assert ret["backend"] == "nccl" and ret["ranks_seen"] == 1
     outs = ret["outs"]
     for kind in ("fake_fp32", "real_fp16"):
-        zf, n_exchanges, graphs, finite_f = outs[(kind, True)]
-        zp, n_plain, _, finite_p = outs[(kind, False)]
+        zf, n_exchanges, graphs, finite_f, n_expected = outs[(kind, True)]
+        zp, n_plain, _, finite_p, _ = outs[(kind, False)]
         assert finite_f and finite_p
-        assert n_plain == 0 and n_exchanges >= 3 + 2  # (2 steps x 2 phases - 1) model forwards + one gather per pad strip
+        # computed from the plans (model forwards + pad-strip pools), not a literal: here (2 steps x 2 phases - 1) + 1
+        assert n_expected >= 4 and n_plain == 0 and n_exchanges == n_expected, (n_exchanges, n_expected)
         assert graphs["eager"] == 0 and graphs["captured"] >= 1
         if kind == "fake_fp32":
             np.testing.assert_array_equal(zf, zp)
