@@ -358,15 +358,20 @@ def main():
             return
         jobs = [dict(prompts=prompt, negative_prompts=negative, seed=sd_, condition_image=cond_img) for sd_ in seeds]
 
+        decoded_here = set()
+
         def on_done(j, z):
             # every rank of the shard group holds the finished latent; ONE of them decodes it (round-robin over the group's
             # ranks), as on one GPU where each image is decoded exactly once -- not g times, once per rank
             if p.sharder.world_size == 1 or wl["tiled"] or j % p.sharder.world_size == p.sharder.rank:
                 state["imgs"] = torch.cat([dec(z[i:i + 1]) for i in range(len(z))])
+                decoded_here.add(j)
 
         kwi = {k: v for k, v in kw.items() if k != "condition_image"}
         p.generate_latents_interleaved(jobs, in_flight=in_flight, on_done=on_done, **kwi)
-        state["latency"] = p.job_latencies()
+        # latency = first kernel of a job (its pad-strip encodes included) to its decoded pixels: only the jobs THIS rank
+        # decoded have the decode inside their interval
+        state["latency"] = p.job_latencies(decoded_here)
 
     def my_seeds(first, count, n_grp, gid):
         """image seeds of this shard group: ``count`` images in total are dealt round-robin to the n_grp groups"""
@@ -392,7 +397,10 @@ def main():
 
     # K timed images IN TOTAL (strong scaling: the work is fixed as N grows); they are dealt to the shard groups
     n_timed = args.steps
-    run_images(pipe, my_seeds(1000, max(args.warmup, 0) * n_groups * m, n_groups, group_id), m)  # W x m images per group
+    # W untimed warm-up images per shard group, rounded up to whole rounds of its m images in flight (every in-flight slot
+    # and every fused batch shape is captured as a hipGraph in the first round; round 3 ran W x m images per group)
+    n_warm = -(-max(args.warmup, 0) // m) * m
+    run_images(pipe, my_seeds(1000, n_warm * n_groups, n_groups, group_id), m)
     timing = (not args.no_kernel_timing)
     if timing:
         fence()

@@ -469,13 +469,16 @@ __device__ __forceinline__ void softmax_slice(int i, f32x16 (&s)[2], float sl, S
 // (a row's scores grew by more than 2^RESCALE_LOG2 over the reference: rare) the tile's softmax is redone exactly
 // (resoftmax_tile; S is recomputed from the K tile still in LDS) -- 16 v_max3 + the shuffle + the decision arithmetic per tile leave the loop (17 % of its VALU issues,
 // and the max -> exp dependency chain at the head of every tile with them).  Slices: two numerators each, pack at 3, 7, 11, 15.
-template <typename T>
+// EXP2 (v_path 6): the scores arrive as exponents already -- the caller folded scale * log2(e) into q and the reference -mb
+// was the initial accumulator value of the S MFMA chain -- so a numerator is ONE v_exp_f32, no FMA.
+template <typename T, bool EXP2>
 __device__ __forceinline__ void softmax_slice_lazy(int i, f32x16 (&s)[2], float sl, SoftmaxRun& r, typename T::v8 (&pf)[4]) {
   if (i == 0) r.psum = 0.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int f = 2 * i + j;
-    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f >> 4][f & 15], sl, -r.mb));
+    const float e = EXP2 ? __builtin_amdgcn_exp2f(s[f >> 4][f & 15])
+                         : __builtin_amdgcn_exp2f(__builtin_fmaf(s[f >> 4][f & 15], sl, -r.mb));
     s[f >> 4][f & 15] = e;
     r.psum += e;
   }
@@ -523,18 +526,19 @@ __device__ __forceinline__ void resoftmax_tile(const uint16_t* kt, int ln, int h
 // One loop iteration's compute (see the header comment): 16 MFMAs -- S_next = K(t+1) Q^T, then O += V(t-1)^T P(t-1)^T --
 // each followed by one slice of the softmax of S_cur; the A operand of MFMA i+1 is fetched from LDS before MFMA i is
 // issued.  sched_barrier(0) pins that order (left to itself the scheduler clusters all MFMAs ahead of the softmax).
-template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY>
+// EXP2: the two S chains start from `negm` (16 registers, every one = -mb of the lane's query row) instead of zeros.
+template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY, bool EXP2>
 __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16_t* v_prev, int lane, int ln, int hi,
                                             const typename T::v8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
                                             const typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4],
-                                            f32x16 (&o)[2], float sl, SoftmaxRun& run) {
+                                            f32x16 (&o)[2], float sl, SoftmaxRun& run, const f32x16& negm) {
   constexpr int NQK = HAS_NEXT ? 8 : 0, N = NQK + (HAS_PV ? 8 : 0);
   auto fetch = [&](int i) -> Vec16 {
     if (i < NQK) return *reinterpret_cast<const Vec16*>(&k_next[(32 * (i & 1) + ln) * K_LD + 16 * (i >> 1) + 8 * hi]);
     const int j = i - NQK;
     return v_frag_tr(v_prev, lane, hi, j >> 1, j & 1);
   };
-  if (HAS_NEXT) {
+  if (HAS_NEXT && !EXP2) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_next[0][i] = s_next[1][i] = 0.f;
   }
@@ -545,7 +549,8 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
     if (i < N) {
       if (i + 1 < N) a_nxt = fetch(i + 1);
       if (i < NQK) {
-        s_next[i & 1] = T::mfma(as_v8<typename T::v8>(a_cur), qf[i >> 1], s_next[i & 1]);
+        if (EXP2 && i < 2) s_next[i & 1] = T::mfma(as_v8<typename T::v8>(a_cur), qf[0], negm);
+        else s_next[i & 1] = T::mfma(as_v8<typename T::v8>(a_cur), qf[i >> 1], s_next[i & 1]);
         asm volatile("" : "+v"(s_next[i & 1]));
       } else {
         const int j = i - NQK;
@@ -553,16 +558,17 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
         asm volatile("" : "+v"(o[j & 1]));
       }
     }
-    if (LAZY) softmax_slice_lazy<T>(i, s_cur, sl, run, p_cur);
+    if (LAZY) softmax_slice_lazy<T, EXP2>(i, s_cur, sl, run, p_cur);
     else softmax_slice<T>(i, s_cur, sl, run, p_cur);
     if (i + 1 < N) a_cur = a_nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <typename T, bool LAZY>
+template <typename T, bool LAZY, bool EXP2 = false>
 __global__ void __launch_bounds__(256, 2)
 k_flash_attn_pipe(const Params p) {
+  static_assert(LAZY || !EXP2, "the exponent-domain variant is built on the lazy-maximum loop");
   constexpr int NK = LAZY ? 3 : 2;
   __shared__ SmemPipe<NK> sm;
   const int tid = threadIdx.x;
@@ -599,15 +605,18 @@ k_flash_attn_pipe(const Params p) {
   const uint32_t k_off = (uint32_t)(((int64_t)st_row * p.k_sn + st_col) * 2), k_half = (uint32_t)(32 * p.k_sn * 2);
   const uint32_t v_off = (uint32_t)(((int64_t)st_row * p.v_sn + st_col) * 2), v_half = (uint32_t)(32 * p.v_sn * 2);
   Vec16 kreg[2], vreg[2];
+  // The whole byte offset goes into the per-lane (VGPR) offset: the hardware range check of a raw buffer load covers
+  // VGPR offset + immediate only, a scalar offset is added AFTER it -- a tile offset passed there would let the
+  // unconditional loads of tiles past the end, and the rows past Nk of a ragged tile, read whatever follows the tensor.
   auto load_k = [&](int t) {
-    const uint32_t base = (uint32_t)t * 2u * k_half;
-    kreg[0] = buf_load16(k_rs, k_off, base);
-    kreg[1] = buf_load16(k_rs, k_off, base + k_half);
+    const uint32_t base = k_off + (uint32_t)t * 2u * k_half;
+    kreg[0] = buf_load16(k_rs, base, 0);
+    kreg[1] = buf_load16(k_rs, base + k_half, 0);
   };
   auto load_v = [&](int t) {
-    const uint32_t base = (uint32_t)t * 2u * v_half;
-    vreg[0] = buf_load16(v_rs, v_off, base);
-    vreg[1] = buf_load16(v_rs, v_off, base + v_half);
+    const uint32_t base = v_off + (uint32_t)t * 2u * v_half;
+    vreg[0] = buf_load16(v_rs, base, 0);
+    vreg[1] = buf_load16(v_rs, base + v_half, 0);
   };
   auto write_k = [&](int buf) {
     *reinterpret_cast<Vec16*>(&sm.k[buf][st_row * K_LD + st_col]) = kreg[0];
@@ -623,8 +632,11 @@ k_flash_attn_pipe(const Params p) {
   for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
   SoftmaxRun run;
   run.mb = -INFINITY, run.l = 0.f, run.mx = 0.f, run.use = 0.f, run.alpha = 1.f, run.psum = 0.f;
-  const float sl = p.scale_log2e;
+  const float sl = EXP2 ? 1.0f : p.scale_log2e;  // EXP2: q arrives multiplied by scale * log2(e)
   const int n_tiles = (p.Nk + KT - 1) / KT, n_full = p.Nk / KT;
+  f32x16 negm;  // EXP2: -mb in every register (the C operand that starts both S chains of a tile)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
   load_k(0);
   load_v(0);
@@ -647,13 +659,27 @@ k_flash_attn_pipe(const Params p) {
                   typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4]) {
     load_k(t + 2);  // unconditional: a tile past the end reads as zeros (buffer bounds check) into a buffer nobody reads
     load_v(t + 1);
-    constexpr bool lazy = LAZY && decltype(has_pv)::value;  // the first tile (no PV yet) always takes the exact softmax
-    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy>(sm.k[kb_next], sm.v[vb_prev], lane, ln, hi, qf,
-                                                                             s_cur, s_next, p_prev, p_cur, oacc, sl, run);
+    // the first tile (no PV yet) takes the exact softmax; EXP2 found its maximum before the loop and is lazy throughout
+    constexpr bool lazy = LAZY && (EXP2 || decltype(has_pv)::value);
+    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2>(sm.k[kb_next], sm.v[vb_prev], lane, ln, hi,
+                                                                                   qf, s_cur, s_next, p_prev, p_cur, oacc, sl,
+                                                                                   run, negm);
     if (lazy) {
       run.alpha = 1.0f;
-      if (__any(!(run.psum <= RESCALE_SUM_MAX)))  // (also catches inf / NaN sums)
+      if (__any(!(run.psum <= RESCALE_SUM_MAX))) {  // (also catches inf / NaN sums)
+        const float mb_old = run.mb;
         resoftmax_tile<T>(sm.k[kb_cur], ln, hi, qf, s_cur, sl, run, p_cur);
+        if (EXP2) {  // S(t+1) was started from the old reference: move it (and the next chains' start) to the new one
+          const float d = run.mb - mb_old;
+          if (decltype(has_next)::value) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s_next[0][i] -= d, s_next[1][i] -= d;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) negm[i] = -run.mb;
+          asm volatile("" : "+v"(negm));
+        }
+      }
       run.l = __builtin_fmaf(run.l, run.alpha, run.psum);
     }
     if (__any(run.alpha != 1.0f)) {  // first tile, or a row's maximum grew by more than 2^RESCALE_LOG2 (rare)
@@ -674,6 +700,18 @@ k_flash_attn_pipe(const Params p) {
 
   if (n_full > 0) {
     qk_tile<T>(sm.k[0], ln, hi, qf, sA);
+    if (EXP2) {  // exact row maximum of tile 0 = the first reference; from here on S is produced relative to it
+      float mx = sA[0][0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) mx = fmaxf(mx, sA[0][j]);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, sA[1][j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      run.mb = mx;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sA[0][i] -= mx, sA[1][i] -= mx, negm[i] = -mx;
+      asm volatile("" : "+v"(negm));
+    }
     // tile 0's iteration ends by overwriting sm.k[0] with tile 2: every wave must be done with the reads above first (inside
     // the loop the barrier that closes iteration t-1 plays that role for the buffer iteration t overwrites)
     __syncthreads();
@@ -876,7 +914,7 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   Params p;
   p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
   hipStream_t st = (hipStream_t)stream;
-  if (v_path == 4 || v_path == 5 || v_path == 8) {  // round 3: 4 / 5 = software-pipelined (5: lazy maximum), 8 = small-KV
+  if (v_path == 4 || v_path == 5 || v_path == 6 || v_path == 8) {  // 4 / 5 / 6 = software-pipelined (5: lazy maximum, 6: + exponent-domain q), 8 = small-KV
     if (v_path == 8 && Nk > 96) return (int)hipErrorInvalidValue;
     // the pipelined kernel addresses K / V with 32-bit byte offsets from the head's base pointer
     if (v_path != 8 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
@@ -894,6 +932,9 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
     } else if (v_path == 5) {
       if (dtype == ED_BF16) k_flash_attn_pipe<BF, true><<<grid, block, 0, st>>>(p);
       else k_flash_attn_pipe<HF, true><<<grid, block, 0, st>>>(p);
+    } else if (v_path == 6) {
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF, true, true><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_pipe<HF, true, true><<<grid, block, 0, st>>>(p);
     } else if (Nk <= 64) {
       if (dtype == ED_BF16) k_flash_attn_smallkv<BF, 2><<<grid, block, 0, st>>>(p);
       else k_flash_attn_smallkv<HF, 2><<<grid, block, 0, st>>>(p);

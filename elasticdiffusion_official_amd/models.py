@@ -90,11 +90,12 @@ FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit
 FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
 VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels
 VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_rows + fp32 GEMM instead of SDPA (AOTriton)
-# _VaeAttention's residual: `attn + x` (False, what has been measured: the permuted first operand makes the sum, and so the
-# rest of the encoder / decoder, channels-last -- MIOpen's NHWC fp32 igemm convolutions, torch GroupNorm) or `x + attn`
-# (True: the VAE stays NCHW -- ed_groupnorm_f32 everywhere, MIOpen's NCHW solvers).  Same values bit for bit; the layout
-# is a speed choice that needs its own MIOpen find records, so it stays off until it has been timed on the GPU.
-VAE_NCHW_RESIDUAL = False
+# _VaeAttention's residual: `x + attn` (True: the VAE stays NCHW -- ed_groupnorm_f32 everywhere, MIOpen's NCHW solvers) or
+# `attn + x` (False, rounds 1-3: the permuted first operand makes the sum, and so the rest of the encoder / decoder,
+# channels-last -- MIOpen's NHWC fp32 igemm convolutions, torch GroupNorm through strided copies).  Same values bit for
+# bit.  Measured on the MI355X, each layout with its own MIOpen find (profiles/r4_s1_vae_layout_ab.jsonl): 8 decode tiles of
+# 128 x 128 latents 979 -> 760 ms, the 128 x 256 decode 202 -> 198 ms, 5 pad-strip encodes 54.9 -> 54.7 ms.
+VAE_NCHW_RESIDUAL = True
 # A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
 for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
     if _name not in globals() or not isinstance(globals()[_name], bool):
@@ -220,14 +221,21 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(cross_dim or dim, inner, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Dropout(0.0)])
 
-    def _fused_weight(self, names):
-        """cat of the projection weights (bias-free in every SD / SDXL attention), rebuilt when a weight changes."""
+    def _fused_weight(self, names, q_scale=None):
+        """cat of the projection weights (bias-free in every SD / SDXL attention), rebuilt when a weight changes.
+        ``q_scale``: factor folded into the first (query) weight -- softmax scale * log2 e for the exponent-domain attention
+        kernel (ops.flash_prescale): the product is formed in fp32 and rounded once, so the scaled 16-bit weight is as close
+        to c * W as the stored one is to W."""
         mods = [getattr(self, n) for n in names]
         key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype, str(m.weight.device)) for m in mods)
         cache = self.__dict__.setdefault("_fused", {})
-        if cache.get(names, (None, None))[0] != key:
-            cache[names] = (key, torch.cat([m.weight.detach() for m in mods], dim=0).contiguous())
-        return cache[names][1]
+        slot = (names, q_scale)
+        if cache.get(slot, (None, None))[0] != key:
+            ws = [m.weight.detach() for m in mods]
+            if q_scale is not None:
+                ws[0] = (ws[0].float() * q_scale).to(ws[0].dtype)
+            cache[slot] = (key, torch.cat(ws, dim=0).contiguous())
+        return cache[slot][1]
 
     def forward(self, x, context=None):
         B, N, _ = x.shape
@@ -236,11 +244,15 @@ class Attention(nn.Module):
                 and (context is None or (_fusable(context) and context.dtype == x.dtype))):
             from . import ops
             if context is None:
+                # exponent-domain kernel: softmax scale * log2 e lives in the query weights (None: natural-domain q)
+                c = ops.flash_prescale(N, N, 3 * inner if FUSED_QKV else inner)
                 if FUSED_QKV:
-                    qkv = F.linear(x, self._fused_weight(("to_q", "to_k", "to_v")))
+                    qkv = F.linear(x, self._fused_weight(("to_q", "to_k", "to_v"), c))
                     q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
                 else:
-                    q, k, v = self.to_q(x), self.to_k(x), self.to_v(x)
+                    q = self.to_q(x) if c is None else F.linear(x, self._fused_weight(("to_q",), c))
+                    k, v = self.to_k(x), self.to_v(x)
+                return self.to_out[0](ops.flash_attention(q, k, v, self.heads, prescaled=c is not None))
             else:
                 q = self.to_q(x)
                 if FUSED_QKV:

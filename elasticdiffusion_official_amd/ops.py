@@ -450,7 +450,7 @@ def softmax_rows_(x, scale=1.0):
     return x
 
 
-VAE_ATTENTION_CHUNK_BYTES = 4 << 30  # score-matrix bytes materialised at a time by vae_attention
+VAE_ATTENTION_CHUNK_BYTES = 1 << 30  # score-matrix bytes materialised at a time by vae_attention (a few thousand rows keep the GEMMs efficient)
 
 
 def vae_attention(q, k, v):
@@ -459,7 +459,8 @@ def vae_attention(q, k, v):
     (N = 32768 tokens for the 1024x2048 decode: 4.3 GB of scores per sample).  Replaces SDPA / AOTriton."""
     B, N, C = q.shape
     scale = C ** -0.5
-    rows = max(256, min(N, VAE_ATTENTION_CHUNK_BYTES // (4 * N * B) // 256 * 256)) if N > 256 else N
+    # rows per chunk: the [B, rows, N] fp32 score block stays under the cap for any B (at least 64 rows)
+    rows = max(64, min(N, VAE_ATTENTION_CHUNK_BYTES // (4 * N * B) // 64 * 64)) if N > 256 else N
     kt = k.transpose(1, 2)
     if rows >= N:
         return torch.bmm(softmax_rows_(torch.bmm(q, kt), scale), v)
@@ -476,33 +477,63 @@ def vae_attention(q, k, v):
 # 848 vs 776 TFLOP/s; N=1024 and the 77-key cross attention: no gain or slower; profiles/r2_s7_probe_attn.jsonl)
 # Round 3: 4 = software-pipelined self-attention kernel, 5 = the same with the lazy row maximum (no per-tile max after the
 # first tile; exact redo when a lane's sum of numerators exceeds 2^6), 8 = small-KV kernel (Nk <= 96: the 77-token cross
-# attention).
+# attention).  Round 4: 6 = 5 on exponent-domain queries (the caller folds scale * log2 e into q -- models.Attention folds it
+# into the query projection weights -- and the reference maximum rides in the MFMA accumulator's initial value, so a
+# numerator is one v_exp_f32: 157 instead of 189 (lazy) / 214 (exact) instructions per 64-key tile and wave).
 FLASH_V_PATH = None
+FLASH_EXP2 = True   # self-attention through v_path 6 where the pipelined kernel applies (see flash_prescale)
 _ENV_VARIANT = __import__("os").environ.get("ED_FLASH_VARIANT")  # A/B: "legacy" = the round-2 choice, or a variant number
+LOG2E = 1.4426950408889634
 
 
-def _flash_variant(B, heads, Nq, Nk, k=None, v=None):
+def _pipe_fits(Nk, row_stride):
+    """The pipelined kernels address K / V with 32-bit byte offsets and want at least two full tiles."""
+    return Nk >= 128 and (Nk + 128) * row_stride * 2 < 2 ** 31
+
+
+def flash_prescale(Nq, Nk, row_stride, scale=0.125):
+    """-> the factor a caller must fold into q (softmax scale * log2 e) to run the exponent-domain kernel (v_path 6) for
+    a self-attention of this shape, or None when that kernel does not apply (then q stays as it is).  ``row_stride``:
+    elements between consecutive tokens of k / v (3 * inner for slices of a fused QKV projection)."""
     if FLASH_V_PATH is not None:
+        want = int(FLASH_V_PATH)
+    elif _ENV_VARIANT is not None:
+        want = -1 if _ENV_VARIANT == "legacy" else int(_ENV_VARIANT)
+    else:
+        want = 6 if FLASH_EXP2 else -1
+    return scale * LOG2E if (want == 6 and _pipe_fits(Nk, row_stride)) else None
+
+
+def _flash_variant(B, heads, Nq, Nk, k=None, v=None, prescaled=False):
+    fits = k is None or _pipe_fits(Nk, max(k.stride(1), v.stride(1)))
+    if prescaled:
+        if not (Nk >= 128 and fits):
+            _reject("flash_attention: exponent-domain q needs the pipelined kernel (Nk >= 128, 32-bit K / V offsets)")
+        return 6
+    if FLASH_V_PATH is not None and int(FLASH_V_PATH) != 6:
         return int(FLASH_V_PATH)
     legacy = 2 if (Nq >= 2048 and Nk >= 1024 and B * heads * (Nq // 256) >= 1024) else 0
     if _ENV_VARIANT == "legacy":
         return legacy
-    if _ENV_VARIANT is not None:
+    if _ENV_VARIANT is not None and int(_ENV_VARIANT) != 6:
         want = int(_ENV_VARIANT)
         if want in (4, 5):
-            fits = k is None or (Nk + 128) * max(k.stride(1), v.stride(1)) * 2 < 2 ** 31
             return want if (Nk >= 128 and fits) else (8 if Nk <= 96 else legacy)
         return want if (want != 8 or Nk <= 96) else legacy
     if Nk <= 96:
         return 8
-    if Nk >= 128 and (k is None or (Nk + 128) * max(k.stride(1), v.stride(1)) * 2 < 2 ** 31):
-        return 4
+    if Nk >= 128 and fits:
+        return FLASH_DEFAULT_PIPE
     return legacy
 
 
-def flash_attention(q, k, v, heads, v_path=None):
+FLASH_DEFAULT_PIPE = 4   # pipelined variant for natural-domain q (4 exact / 5 lazy maximum)
+
+
+def flash_attention(q, k, v, heads, v_path=None, prescaled=False):
     """q [B,Nq,H*64], k / v [B,Nk,H*64] 16-bit (last dim contiguous; batch / token strides free, so column slices of a
-    fused QKV projection are fine) -> softmax(q k^T / 8) v as a contiguous [B,Nq,H*64] tensor.  See ed_flash_attention."""
+    fused QKV projection are fine) -> softmax(q k^T / 8) v as a contiguous [B,Nq,H*64] tensor.  ``prescaled``: q already
+    carries the factor ``flash_prescale`` returned (exponent-domain kernel, v_path 6).  See ed_flash_attention."""
     B, Nq, HD = q.shape
     Nk = k.shape[1]
     if HD != heads * 64 or k.shape != (B, Nk, HD) or v.shape != (B, Nk, HD):
@@ -515,11 +546,13 @@ def flash_attention(q, k, v, heads, v_path=None):
             _LAUNCH["device"] = t.device
         elif _LAUNCH["device"] != t.device:
             _reject(f"flash_attention: {name} lives on {t.device}, q on {_LAUNCH['device']}")
+    if v_path is not None and (int(v_path) == 6) != bool(prescaled):
+        _reject("flash_attention: v_path 6 takes exponent-domain q (prescaled=True) and nothing else does")
     out = torch.empty(B, Nq, HD, dtype=q.dtype, device=q.device)
     # algorithmic work: QK^T and PV contractions (4 B H Nq Nk 64 flop); q, k, v read once, out written once
     TIMER.note_work("ed_flash_attention", flops=4.0 * B * heads * Nq * Nk * 64,
                     nbytes=2.0 * q.element_size() * HD * B * (Nq + Nk))
     _call("ed_flash_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _code(q, "q"), B, heads, Nq, Nk,
           64, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
-          0.125, _flash_variant(B, heads, Nq, Nk, k, v) if v_path is None else int(v_path), _stream())
+          0.125, _flash_variant(B, heads, Nq, Nk, k, v, prescaled) if v_path is None else int(v_path), _stream())
     return out

@@ -728,14 +728,14 @@ class ElasticDiffusion(nn.Module):
             # on geometry and schedule, so the first job takes the ones _setup_run just made and each later job
             # recomputes identical ones); cache_backgrounds=True is the explicit opt-in to share them (ADVICE r2:
             # otherwise the N-GPU bench line amortises 100 VAE encodes the 1-GPU line pays per image)
+            with torch.cuda.device(self.device):  # a job's clock starts BEFORE its pad-strip encodes
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
+            self.job_events[j] = [ev0, None]
             frames = None
             if started[0] and not self.cache_backgrounds:
                 frames = (self._strip_frames(S.P.gpad, self._timesteps, S.C), self._strip_frames(S.P.vpad, self._timesteps, S.C))
             started[0] += 1
-            with torch.cuda.device(self.device):
-                ev0 = torch.cuda.Event(enable_timing=True)
-                ev0.record(torch.cuda.current_stream(self.device))
-            self.job_events[j] = [ev0, None]
             prog = self._program(S, job["prompts"], job.get("negative_prompts", ""), job.get("condition_image"),
                                  direct=False, frames=frames)
             with rng:
@@ -787,12 +787,15 @@ class ElasticDiffusion(nn.Module):
         self._mark("loop_done")
         return results
 
-    def job_latencies(self):
-        """-> seconds from the start of each job of the last ``generate_latents_interleaved`` call to the end of its
-        ``on_done`` (decode), in job order; synchronises.  With m images in flight the throughput is ~m images per
-        latency: bench.py reports both so a throughput-scaling line cannot be read as a per-image speed-up."""
+    def job_latencies(self, jobs=None):
+        """-> seconds from the start of each job of the last ``generate_latents_interleaved`` call (its first pad-strip
+        encode; the first job's frames are made by the shared setup just before) to the end of its ``on_done`` (decode), in
+        job order; synchronises.  ``jobs``: only these job indices (a rank that did not decode a job has no decode inside
+        that job's interval).  With m images in flight the throughput is ~m images per latency: bench.py reports both so a
+        throughput-scaling line cannot be read as a per-image speed-up."""
         torch.cuda.synchronize(self.device)
-        return [1e-3 * a.elapsed_time(b) for _, (a, b) in sorted(self.job_events.items()) if b is not None]
+        return [1e-3 * a.elapsed_time(b) for j, (a, b) in sorted(self.job_events.items())
+                if b is not None and (jobs is None or j in jobs)]
 
     @_on_own_device
     @torch.no_grad()

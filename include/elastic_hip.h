@@ -297,6 +297,12 @@ int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const flo
  *   first tile (numerators against the standing reference; exact redo of a tile whose sum exceeds 2^6).  8 = small-KV kernel for Nk <= 96 (cross
  *   attention on the 77 text tokens: K / V staged once per 512 query rows, single pass, no online rescale).
  *   4, 5 and 8 agree with 0..3 to the rounding of P (same fp32 accumulation, different summation grouping).
+ *   6 = 5 for EXPONENT-DOMAIN queries: the caller has multiplied q by scale * log2(e) (the model folds it into the query
+ *   projection weights), `scale` is ignored and out = sum_k 2^(q.k) v / sum_k 2^(q.k).  The row reference -m is the initial
+ *   value of the S accumulators (the MFMA's C operand), so a numerator is one v_exp_f32 of the accumulator: no FMA, no
+ *   per-tile maximum (exact maximum of the first tile, then the lazy check of 5).  Same limits as 4 / 5; Nk >= 64.
+ *   K / V tile loads of 4, 5, 6 carry their whole byte offset in the per-lane offset: rows past Nk read as zeros by the
+ *   buffer range check, which does not cover a scalar offset.
  */
 int ed_flash_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,
                        int head_dim, int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,

@@ -238,20 +238,32 @@ def test_flash_variant_heuristic():
     from elasticdiffusion_official_amd import ops
     # round 3 (profiles/r3_s2_probe_attn.jsonl): the pipelined kernel wins or ties on every self-attention shape, the
     # small-KV kernel on the 77-token cross attention
-    assert ops._flash_variant(20, 10, 4096, 4096) == 4   # SDXL level-2 self attention
-    assert ops._flash_variant(20, 20, 1024, 1024) == 4   # level 3
+    pipe = ops.FLASH_DEFAULT_PIPE
+    assert pipe in (4, 5)
+    assert ops._flash_variant(20, 10, 4096, 4096) == pipe   # SDXL level-2 self attention, natural-domain q
+    assert ops._flash_variant(20, 20, 1024, 1024) == pipe   # level 3
+    assert ops._flash_variant(20, 10, 4096, 4096, prescaled=True) == 6   # exponent-domain q (models.Attention, self-attention)
     assert ops._flash_variant(20, 10, 4096, 77) == 8     # cross attention (Nk <= 96)
     assert ops._flash_variant(1, 10, 4096, 100) == 0     # neither: one full tile + a ragged one
     class _Strided:   # stand-in for a k / v tensor with a huge token stride: 32-bit K offsets would overflow -> round-2 kernel
         def stride(self, dim):
             return 2 ** 20
     assert ops._flash_variant(20, 10, 4096, 4096, _Strided(), _Strided()) == 2
-    saved = ops.FLASH_V_PATH
+    # which shapes get exponent-domain queries: self-attention with >= 2 full key tiles and 32-bit addressable K / V
+    c = 0.125 * 1.4426950408889634
+    assert ops.flash_prescale(4096, 4096, 3 * 640) == c and ops.flash_prescale(1024, 1024, 1280) == c
+    assert ops.flash_prescale(64, 64, 3 * 1280) is None and ops.flash_prescale(4096, 4096, 2 ** 20) is None
+    saved = ops.FLASH_V_PATH, ops.FLASH_EXP2
     try:
+        ops.FLASH_EXP2 = False
+        assert ops.flash_prescale(4096, 4096, 3 * 640) is None
+        ops.FLASH_EXP2 = True
         ops.FLASH_V_PATH = 1
-        assert ops._flash_variant(20, 10, 4096, 4096) == 1
+        assert ops._flash_variant(20, 10, 4096, 4096) == 1 and ops.flash_prescale(4096, 4096, 3 * 640) is None
+        ops.FLASH_V_PATH = 6   # forcing 6 only applies where the caller really pre-scaled q
+        assert ops.flash_prescale(4096, 4096, 3 * 640) == c and ops._flash_variant(20, 10, 4096, 77) == 8
     finally:
-        ops.FLASH_V_PATH = saved
+        ops.FLASH_V_PATH, ops.FLASH_EXP2 = saved
 
 
 def test_miopen_db_derivation_is_idempotent_and_well_formed(tmp_path):
@@ -349,4 +361,7 @@ def test_pipelined_attention_schedule_emulation():
             got, slow_tiles = emu.softmax_schedule(sc, v, 0.18, lazy)
             assert np.abs(got - want).max() < 1e-12
             slow_total += slow_tiles
+        got, slow6 = emu.exp2_schedule(sc, v)            # v_path 6: reference carried in the S accumulators' initial value
+        assert np.abs(got - emu.reference(sc, v, 1.0)).max() < 1e-12
+        slow_total += slow6
     assert slow_total > 0   # the slow path was exercised

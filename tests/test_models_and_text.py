@@ -172,29 +172,32 @@ def test_weights_snapshot_end_to_end_on_gpu(tmp_path):
 
 
 def test_vae_attention_residual_order_switch_changes_layout_not_values():
-    """models.VAE_NCHW_RESIDUAL (off by default): `x + attn` keeps the VAE NCHW, `attn + x` makes everything after the
+    """models.VAE_NCHW_RESIDUAL (on since round 4): `x + attn` keeps the VAE NCHW, `attn + x` makes everything after the
     mid-block attention channels-last; IEEE addition commutes, so the two decodes are bit-identical."""
     import torch
     from elasticdiffusion_official_amd import models
     torch.manual_seed(0)
     att = models._VaeAttention(64).float()
     x = torch.randn(2, 64, 8, 8)
-    assert models.VAE_NCHW_RESIDUAL is False
+    saved = models.VAE_NCHW_RESIDUAL
+    assert saved is True
     try:
+        models.VAE_NCHW_RESIDUAL = False
         a = att(x)
         models.VAE_NCHW_RESIDUAL = True
         b = att(x)
     finally:
-        models.VAE_NCHW_RESIDUAL = False
+        models.VAE_NCHW_RESIDUAL = saved
     assert torch.equal(a, b)
     assert a.is_contiguous(memory_format=torch.channels_last) and not a.is_contiguous()
     assert b.is_contiguous()
     vae = models.AutoencoderKL(block_out_channels=(32, 64), latent_channels=4).float()
     z = torch.randn(1, 4, 8, 8)
     try:
+        models.VAE_NCHW_RESIDUAL = False
         d0 = vae.decode(z).sample
         models.VAE_NCHW_RESIDUAL = True
         d1 = vae.decode(z).sample
     finally:
-        models.VAE_NCHW_RESIDUAL = False
+        models.VAE_NCHW_RESIDUAL = saved
     assert torch.allclose(d0, d1, rtol=0, atol=1e-5)   # conv algorithms may differ with the layout on CPU too

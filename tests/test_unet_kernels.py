@@ -187,15 +187,35 @@ def test_unet_fused_vs_unfused_close():
 # ---------------------------------------------------------------------------------------------------
 # round 2: flash attention, fused residual adds
 # ---------------------------------------------------------------------------------------------------
-def _attn_ref(q, k, v, H):
+def _attn_ref(q, k, v, H, scale=0.125):
     """fp32 PyTorch reference of the op: softmax(q k^T / sqrt(64)) v per head, on the same 16-bit inputs."""
     B, Nq, HD = q.shape
     qf, kf, vf = (t.float().view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v))
-    s = qf @ kf.transpose(-1, -2) * 0.125
+    s = qf @ kf.transpose(-1, -2) * scale
     return (torch.softmax(s, dim=-1) @ vf).transpose(1, 2).reshape(B, Nq, HD)
 
 
-@pytest.mark.parametrize("v_path", [0, 1, 2, 3, 4, 5, 8])  # bit 0: V staging; bit 1: 64 rows/wave; 4, 5: pipelined; 8: small-KV
+LN2 = 0.6931471805599453
+
+
+def _exp2_q(q):
+    """Exponent-domain queries for v_path 6: q * (softmax scale * log2 e), rounded once to the 16-bit type (what
+    models.Attention folds into the query projection weights).  The op on them is softmax base 2 = softmax(ln 2 * q' k^T)."""
+    return (q.float() * (0.125 * 1.4426950408889634)).to(q.dtype)
+
+
+def _flash(ops, q, k, v, H, v_path):
+    """ops.flash_attention for any variant, plus the fp32 reference and SDPA on the inputs that variant really sees."""
+    if v_path == 6:
+        q = _exp2_q(q)
+    got = ops.flash_attention(q, k, v, H, v_path=v_path, prescaled=v_path == 6)
+    B, Nq = q.shape[:2]
+    scale = LN2 if v_path == 6 else 0.125
+    sdpa = F.scaled_dot_product_attention(*(t.reshape(B, -1, H, 64).transpose(1, 2) for t in (q, k, v)), scale=scale)
+    return got, _attn_ref(q, k, v, H, scale), sdpa.transpose(1, 2).reshape(B, Nq, H * 64)
+
+
+@pytest.mark.parametrize("v_path", [0, 1, 2, 3, 4, 5, 6, 8])  # bit 0: V staging; bit 1: 64 rows/wave; 4, 5, 6: pipelined; 8: small-KV
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 10, 4096, 4096), (3, 20, 1024, 1024), (2, 20, 1024, 77), (1, 10, 4096, 77),
                                        (2, 2, 256, 256), (1, 4, 64, 64), (1, 1, 100, 77), (2, 3, 200, 333), (1, 2, 1, 1)])
@@ -204,13 +224,12 @@ def test_flash_attention(dtype, B, H, Nq, Nk, v_path):
     from elasticdiffusion_official_amd import ops
     if v_path == 8 and Nk > 96:
         pytest.skip("the small-KV kernel takes Nk <= 96")
+    if v_path == 6 and Nk < 128:
+        pytest.skip("the exponent-domain kernel takes Nk >= 128 (ops.flash_prescale)")
     g = torch.Generator(device=DEV).manual_seed(Nq * 7 + Nk)
     q, k, v = (torch.randn(B, n, H * 64, device=DEV, generator=g).mul(s).to(dtype) for n, s in ((Nq, 1.5), (Nk, 1.5), (Nk, 1.0)))
-    got = ops.flash_attention(q, k, v, H, v_path=v_path)
+    got, ref, sdpa = _flash(ops, q, k, v, H, v_path)
     assert got.shape == (B, Nq, H * 64) and got.is_contiguous()
-    ref = _attn_ref(q, k, v, H)
-    sdpa = F.scaled_dot_product_attention(*(t.view(B, -1, H, 64).transpose(1, 2) for t in (q, k, v)))
-    sdpa = sdpa.transpose(1, 2).reshape(B, Nq, H * 64)
     err = float((got.float() - ref).abs().max())
     err_sdpa = float((sdpa.float() - ref).abs().max())
     rel = float((got.float() - ref).norm() / ref.norm())
@@ -242,11 +261,37 @@ def test_flash_attention_strided_inputs_and_outlier_rows():
         assert torch.equal(again, base)  # strides, the V staging path and the rows-per-wave variant do not change a bit
     # the pipelined kernel (deferred rescale: the outlier row takes the rescale branch in a late tile) on strided and on
     # contiguous inputs: identical to itself, and within the rounding of P of the others
-    for path in (4, 5):
-        piped = ops.flash_attention(q, k, v, H, v_path=path)
-        assert torch.equal(piped, ops.flash_attention(q.contiguous(), k.contiguous(), v.contiguous(), H, v_path=path))
+    for path in (4, 5, 6):
+        qq = _exp2_q(q) if path == 6 else q
+        kw = dict(v_path=path, prescaled=path == 6)
+        piped = ops.flash_attention(qq, k, v, H, **kw)
+        assert torch.equal(piped, ops.flash_attention(qq.contiguous(), k.contiguous(), v.contiguous(), H, **kw))
         assert float((piped.float() - ref).abs().max()) < 3e-2
         assert float((piped[0, 5, :64].float() - v[0, 600, :64].float()).abs().max()) < 3e-2
+        assert float((piped[1, 7].float() - v[1].float().mean(0)).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Nk", [130, 333, 192, 4096])
+def test_flash_attention_never_reads_past_the_keys(dtype, Nk):
+    """the pipelined kernels issue the loads of tiles t+1 / t+2 unconditionally and leave the rows past Nk of
+    a ragged tile to the buffer range check -- so K and V sit at the END of an allocation whose tail is poisoned with NaN /
+    Inf: a load that escaped the range check (an offset the check does not cover) would turn the output non-finite or wrong."""
+    from elasticdiffusion_official_amd import ops
+    B, H, Nq = 2, 3, 256
+    g = torch.Generator(device=DEV).manual_seed(Nk)
+    tail = 3 * 64 * H * 64                      # three tiles' worth of poison behind the last key row of the last batch
+    pool = torch.empty(2, B * Nk * H * 64 + tail, device=DEV, dtype=dtype)
+    pool[:, B * Nk * H * 64:] = float("nan")
+    pool[:, B * Nk * H * 64::2] = float("inf")
+    k, v = (pool[i, :B * Nk * H * 64].view(B, Nk, H * 64) for i in range(2))
+    k.copy_(torch.randn(B, Nk, H * 64, device=DEV, generator=g))
+    v.copy_(torch.randn(B, Nk, H * 64, device=DEV, generator=g))
+    q = torch.randn(B, Nq, H * 64, device=DEV, generator=g).to(dtype)
+    for path in (4, 5, 6, 0):
+        got, ref, _ = _flash(ops, q, k, v, H, path)
+        assert bool(torch.isfinite(got).all()), path
+        assert float((got.float() - ref).abs().max()) < (3e-2 if dtype == torch.bfloat16 else 6e-3), path
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -267,9 +312,8 @@ def test_flash_attention_deferred_rescale_branches(dtype):
         kh[0, 64 * tile, 0] = (qh[0, 3, 0].float() * (0.35 * tile * 8.0 / float(qh[0, 3, 0].float().pow(2).sum()))).to(dtype)
     kh[0, 900, 1] = (qh[0, 9, 1].float().sign() * 6.0).to(dtype)   # (b) head 1, query 9: a huge score in tile 14
     kh[0, 5, 1] = (qh[0, 17, 1].float().sign() * 6.0).to(dtype)     # (c) head 1, query 17: the largest score in tile 0
-    ref = _attn_ref(q, k, v, H)
-    for path in (4, 5, 0):
-        got = ops.flash_attention(q, k, v, H, v_path=path)
+    for path in (4, 5, 6, 0):
+        got, ref, _ = _flash(ops, q, k, v, H, path)
         err = float((got.float() - ref).abs().max())
         assert err < (2e-2 if dtype == torch.bfloat16 else 4e-3), (path, err)
 

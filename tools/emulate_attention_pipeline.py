@@ -165,6 +165,38 @@ def softmax_schedule(scores, v, sl, lazy):
     return o / (lanes[0]["l"] + lanes[1]["l"]), slow_tiles
 
 
+def exp2_schedule(scores, v):
+    """v_path 6 (exponent-domain q: ``scores`` are exponents already, sl = 1): the S chains of tile t+1 start from -mb AS OF
+    ITERATION t (the MFMA C operand ``negm``), a numerator is 2^S with no subtraction, and a slow-path tile (lazy check failed)
+    moves the reference, the already started S(t+1) and ``negm`` by the same amount.  -> (out[D], slow-path tiles)."""
+    n, D = scores.shape[0], v.shape[2]
+    mb = scores[0].max()                       # prologue: exact maximum of tile 0 (both lanes, after the shuffle)
+    negm = -mb
+    s_cur = scores[0] - mb                     # sA -= mx
+    l, o, p_prev, slow_tiles = [0.0, 0.0], np.zeros(D), None, 0
+    for t in range(n):
+        s_next = scores[t + 1] + negm if t + 1 < n else None      # region: S(t+1) = K(t+1) Q'^T + negm
+        if p_prev is not None:
+            o += p_prev @ v[t - 1]                                 # region: O += V(t-1)^T P(t-1)^T (old reference)
+        p = 2.0 ** s_cur                                           # lazy slices: one exp2 per value
+        psum, alpha = [p[:32].sum(), p[32:].sum()], 1.0
+        if not all(x <= 2.0 ** RESCALE_LOG2 for x in psum):        # __any(!(psum <= 2^6)): resoftmax_tile from the raw scores
+            slow_tiles += 1
+            use = max(mb, scores[t].max())
+            alpha, d, mb = 2.0 ** (mb - use), use - mb, use
+            p = 2.0 ** (scores[t] - use)
+            psum = [p[:32].sum(), p[32:].sum()]
+            if s_next is not None:
+                s_next = s_next - d
+            negm = -mb
+        for h in (0, 1):
+            l[h] = l[h] * alpha + psum[h]
+        o *= alpha
+        p_prev, s_cur = p, s_next
+    o += p_prev @ v[n - 1]
+    return o / (l[0] + l[1]), slow_tiles
+
+
 def reference(scores, v, sl):
     x = scores.reshape(-1) * sl
     p = 2.0 ** (x - x.max())
@@ -193,3 +225,16 @@ if __name__ == "__main__":
             worst = max(worst, np.abs(got - reference(sc, v, 0.18)).max())
             slow += s_
         print(f"lazy={lazy}: max |err| vs plain softmax {worst:.2e}, slow-path tiles {slow}")
+    worst, slow = 0.0, 0
+    for trial in range(30):
+        n = int(rng.integers(1, 12))
+        sc = rng.normal(size=(n, 64)) * 3.0
+        if trial % 3 == 0 and n > 2:
+            sc[n - 2, 7] += 60.0
+        if trial % 3 == 1:
+            sc += np.arange(n)[:, None] * 2.5
+        v = rng.normal(size=(n, 64, 8))
+        got, s_ = exp2_schedule(sc, v)
+        worst = max(worst, np.abs(got - reference(sc, v, 1.0)).max())
+        slow += s_
+    print(f"exp2 (v_path 6): max |err| vs plain softmax {worst:.2e}, slow-path tiles {slow}")

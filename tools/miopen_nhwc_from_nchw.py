@@ -179,7 +179,11 @@ def derive_find_records(dtype="FP16"):
             for rec in v.split(";"):
                 name, rest = rec.split(":", 1)
                 t, ws, algo = rest.split(",")
-                out.append(f"{name}:{float(t) * n / n0:.6g},{int(int(ws) * n / n0)},{algo}")
+                # workspace: scaled with the batch, rounded UP to 256 B (a truncated estimate could be smaller than what the
+                # solver needs for the derived batch -- ADVICE r3); zero stays zero
+                ws_n = -(-int(ws) * n // n0)
+                ws_n = -(-ws_n // 256) * 256 if ws_n else 0
+                out.append(f"{name}:{float(t) * n / n0:.6g},{ws_n},{algo}")
             key = "-".join(list(shape[:7]) + [str(n)] + list(shape[7:])) + suffix
             ufdb[key] = ";".join(out)
             added += 1
