@@ -88,6 +88,9 @@ FUSED_ADD_LAYERNORM = True  # BasicTransformerBlock: residual add + next LayerNo
 FUSED_TOKENS_ADD = True     # Transformer2DModel: tokens -> NCHW + residual in one kernel (ed_tokens_add_nchw)
 FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit) instead of SDPA / AOTriton
 FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
+HIP_GEGLU_GEMM = True       # GEGLU: projection GEMM with the gated product in its epilogue (ed_geglu_gemm) instead of hipBLASLt + ed_geglu
+HIP_LINEAR = True           # the projections where ed_linear measured faster than hipBLASLt (ops.linear_wins)
+HIP_CONV3X3 = True          # ResnetBlock2D / Upsample2D 3x3 convolutions, channels-last: ed_conv3x3_nhwc (+bias, +temb, +residual) instead of MIOpen
 VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels
 VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_rows + fp32 GEMM instead of SDPA (AOTriton)
 # _VaeAttention's residual: `x + attn` (True: the VAE stays NCHW -- ed_groupnorm_f32 everywhere, MIOpen's NCHW solvers) or
@@ -105,14 +108,39 @@ for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
 
 def fused_unet_entry_points():
     """C-ABI entry points a 16-bit UNet forward reaches with the current switches (the real-architecture parity test
-    checks that they were actually launched, i.e. that no torch fallback silently took over)."""
-    on = [("ed_groupnorm_nhwc" if CHANNELS_LAST else "ed_groupnorm", FUSED_KERNELS), ("ed_geglu", FUSED_KERNELS),
+    checks that they were actually launched, i.e. that no torch fallback silently took over).  ed_linear / ed_conv3x3_nhwc
+    take only the shapes they win on (ops.linear_wins / conv3x3_ok), so they are not REQUIRED of every model; where the
+    convolution kernel runs, its epilogue has replaced ed_bias_residual_add."""
+    hip_conv = FUSED_KERNELS and HIP_CONV3X3 and CHANNELS_LAST
+    on = [("ed_groupnorm_nhwc" if CHANNELS_LAST else "ed_groupnorm", FUSED_KERNELS),
+          ("ed_geglu_gemm" if HIP_GEGLU_GEMM else "ed_geglu", FUSED_KERNELS),
           ("ed_layernorm", FUSED_KERNELS and FUSED_LAYERNORM),
           ("ed_flash_attention", FUSED_KERNELS and FLASH_ATTENTION),
           ("ed_add_layernorm", FUSED_KERNELS and FUSED_ADD_LAYERNORM),
           ("ed_tokens_add_nchw", FUSED_KERNELS and FUSED_TOKENS_ADD and not CHANNELS_LAST),
-          ("ed_bias_residual_add", FUSED_KERNELS and FUSED_CONV_BIAS and FUSED_TEMB_ADD)]
+          ("ed_bias_residual_add", FUSED_KERNELS and FUSED_CONV_BIAS and FUSED_TEMB_ADD and not hip_conv)]
     return {n for n, flag in on if flag}
+
+
+def linear_(x, weight, bias=None):
+    """F.linear, through ed_linear for the 16-bit shapes it measured faster on (ops.linear_wins), hipBLASLt otherwise."""
+    if HIP_LINEAR and FUSED_KERNELS and _fusable(x) and weight.dtype == x.dtype and weight.is_contiguous():
+        from . import ops
+        if ops.linear_wins(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]):
+            return ops.linear(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+def _hip_conv3x3(x, conv):
+    """Can ``conv`` (3x3, stride 1, padding 1) on the channels-last 16-bit activation ``x`` run as ed_conv3x3_nhwc?"""
+    if not (HIP_CONV3X3 and _fusable_nhwc(x)):
+        return False
+    w = conv.weight
+    if w.dtype != x.dtype or not w.is_contiguous(memory_format=torch.channels_last):
+        return False
+    from . import ops
+    B, C, H, W = x.shape
+    return ops.conv3x3_ok(B, H, W, C, w.shape[0])
 
 
 def layer_norm(norm, x):
@@ -182,6 +210,15 @@ class ResnetBlock2D(nn.Module):
         sc = self.conv_shortcut
         cout = self.conv1.out_channels
         cl = _fusable_nhwc(x) and cout % 8 == 0 and cout // self.norm2.num_groups >= 8
+        if cl and _hip_conv3x3(x, self.conv1) and self.conv2.weight.is_contiguous(memory_format=torch.channels_last):
+            # both convolutions as ed_conv3x3_nhwc: conv1's epilogue adds its bias and the time embedding, conv2's its bias and
+            # the block's residual -- the two broadcast adds and the closing add never exist as separate passes
+            from . import ops
+            h = ops.conv3x3_nhwc(group_norm_act(self.norm1, x, silu=True), self.conv1.weight, self.conv1.bias,
+                                 sample_bias=None if tb is None else tb.contiguous())
+            a = group_norm_act(self.norm2, h, silu=True)
+            res = x if sc is None else linear_(x.permute(0, 2, 3, 1), sc.weight.reshape(cout, -1), sc.bias).permute(0, 3, 1, 2)
+            return ops.conv3x3_nhwc(a, self.conv2.weight, self.conv2.bias, residual=res)
         if FUSED_CONV_BIAS and FUSED_TEMB_ADD and (cl or (_fusable(x) and (x.shape[2] * x.shape[3]) % 8 == 0)):
             # MIOpen adds a convolution's bias with a separate broadcast kernel: run the convolutions bias-free and fold
             # conv1's bias (+ temb) into norm2's passes, conv2's and the shortcut's into the closing residual add
@@ -247,20 +284,21 @@ class Attention(nn.Module):
                 # exponent-domain kernel: softmax scale * log2 e lives in the query weights (None: natural-domain q)
                 c = ops.flash_prescale(N, N, 3 * inner if FUSED_QKV else inner)
                 if FUSED_QKV:
-                    qkv = F.linear(x, self._fused_weight(("to_q", "to_k", "to_v"), c))
+                    qkv = linear_(x, self._fused_weight(("to_q", "to_k", "to_v"), c))
                     q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
                 else:
-                    q = self.to_q(x) if c is None else F.linear(x, self._fused_weight(("to_q",), c))
+                    q = linear_(x, self.to_q.weight if c is None else self._fused_weight(("to_q",), c))
                     k, v = self.to_k(x), self.to_v(x)
-                return self.to_out[0](ops.flash_attention(q, k, v, self.heads, prescaled=c is not None))
+                o = ops.flash_attention(q, k, v, self.heads, prescaled=c is not None)
+                return linear_(o, self.to_out[0].weight, self.to_out[0].bias)
             else:
-                q = self.to_q(x)
+                q = linear_(x, self.to_q.weight)
                 if FUSED_QKV:
                     kv = F.linear(context, self._fused_weight(("to_k", "to_v")))
                     k, v = kv[..., :inner], kv[..., inner:]
                 else:
                     k, v = self.to_k(context), self.to_v(context)
-            return self.to_out[0](ops.flash_attention(q, k, v, self.heads))
+            return linear_(ops.flash_attention(q, k, v, self.heads), self.to_out[0].weight, self.to_out[0].bias)
         ctx = x if context is None else context
         q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
@@ -275,6 +313,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim, inner * 2)
 
     def forward(self, x):
+        if HIP_GEGLU_GEMM and FUSED_KERNELS and _fusable(x) and self.proj.weight.dtype == x.dtype:
+            from . import ops
+            if ops.geglu_gemm_ok(x.numel() // x.shape[-1], x.shape[-1], self.proj.out_features // 2):
+                return ops.geglu_gemm(x, self.proj.weight, self.proj.bias)
         y = self.proj(x)
         if _fusable(y) and (y.shape[-1] // 2) % 8 == 0:
             from . import ops
@@ -289,7 +331,7 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
 
     def forward(self, x):
-        return self.net[2](self.net[0](x))
+        return linear_(self.net[0](x), self.net[2].weight, self.net[2].bias)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -326,7 +368,7 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, context):
         B, C, H, W = x.shape
         if self.linear_proj:
-            h = self.proj_in(group_norm_act(self.norm, x, tokens=True))
+            h = linear_(group_norm_act(self.norm, x, tokens=True), self.proj_in.weight, self.proj_in.bias)
         else:
             h = self.proj_in(group_norm_act(self.norm, x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         pend = None
@@ -334,7 +376,7 @@ class Transformer2DModel(nn.Module):
             pend, h = blk(h, context, pend)
         h = pend + h
         if self.linear_proj:
-            h = self.proj_out(h)
+            h = linear_(h, self.proj_out.weight, self.proj_out.bias)
             if (FUSED_TOKENS_ADD and _fusable(x) and _fusable(h) and C % 64 == 0 and (H * W) % 64 == 0):
                 from . import ops
                 return ops.tokens_add_nchw(x, h)  # x + h^T in one pass through an LDS tile
@@ -362,7 +404,11 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        up = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if _hip_conv3x3(up, self.conv):
+            from . import ops
+            return ops.conv3x3_nhwc(up, self.conv.weight, self.conv.bias)
+        return self.conv(up)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -329,6 +329,93 @@ def geglu(x2, inner):
     return out
 
 
+# ---- dense contractions (csrc/gemm_kernels.hip) ---------------------------------------------------------------------
+GEMM_BM, GEMM_BN = 256, 128   # rows / value columns of one workgroup tile (256 output columns for the plain epilogue)
+GEMM_MIN_BLOCKS = 96          # below this many workgroups the 256-CU chip is mostly idle: the library call stays
+
+
+def _gemm_x(x, name):
+    """A [..., K] activation as the kernel sees it: M rows of K contiguous 16-bit values."""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16):
+        _reject(f"{name} must be a 16-bit tensor on the MI355X; no CPU fallback")
+    if not x.is_contiguous():
+        _reject(f"{name} must be contiguous")
+    return x.numel() // x.shape[-1], x.shape[-1]
+
+
+def geglu_gemm_ok(M, K, I):
+    return K % 64 == 0 and K >= 64 and I % GEMM_BN == 0 and M * K * 2 < 2 ** 31 - 16 and 2 * I * K * 2 < 2 ** 31 - 16
+
+
+def geglu_gemm(x, w, bias=None):
+    """x [..., K], w [2I, K], bias [2I] -> [..., I] = (x w_v^T + b_v) * gelu(x w_g^T + b_g).  See ed_geglu_gemm."""
+    M, K = _gemm_x(x, "x")
+    I = w.shape[0] // 2
+    if tuple(w.shape) != (2 * I, K) or not geglu_gemm_ok(M, K, I):
+        _reject(f"geglu_gemm: unsupported shape x {tuple(x.shape)} w {tuple(w.shape)}")
+    out = torch.empty(x.shape[:-1] + (I,), dtype=x.dtype, device=x.device)
+    TIMER.note_work("ed_geglu_gemm", flops=4.0 * M * K * I, nbytes=2.0 * (M * K + 2 * I * K + M * I))
+    _call("ed_geglu_gemm", _dev(x, None, "x"), _dev(w, x.dtype, "w"), _opt(bias, x.dtype, "bias"), _dev(out, None, "out"),
+          _code(x, "x"), M, K, I, _stream())
+    return out
+
+
+def linear_ok(M, K, N):
+    return (K % 64 == 0 and K >= 64 and N % 8 == 0 and M * K * 2 < 2 ** 31 - 16 and N * K * 2 < 2 ** 31 - 16
+            and -(-M // GEMM_BM) * -(-N // (2 * GEMM_BN)) >= GEMM_MIN_BLOCKS)
+
+
+def linear_wins(M, K, N):
+    """Where ed_linear measured faster than hipBLASLt on the MI355X in fp16 (profiles/r4_s1_gemm_first_run_fp16.json: all
+    K = 640 projections 1.1-1.7 x, K = 2560 -> 640 1.12 x; the K = 1280 / 5120 projections 0.91-0.95 x: hipBLASLt stays)."""
+    return linear_ok(M, K, N) and (K <= 640 or (K >= 2560 and N <= 640))
+
+
+def linear(x, w, bias=None, residual=None):
+    """x [..., K], w [N, K] -> x w^T + bias (+ residual [..., N]).  See ed_linear."""
+    M, K = _gemm_x(x, "x")
+    N = w.shape[0]
+    if tuple(w.shape) != (N, K) or not linear_ok(M, K, N):
+        _reject(f"linear: unsupported shape x {tuple(x.shape)} w {tuple(w.shape)}")
+    out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    if residual is not None and (residual.shape != out.shape or residual.dtype != x.dtype):
+        _reject("linear: residual must match the output")
+    TIMER.note_work("ed_linear", flops=2.0 * M * K * N, nbytes=2.0 * (M * K + N * K + M * N * (2 if residual is not None else 1)))
+    _call("ed_linear", _dev(x, None, "x"), _dev(w, x.dtype, "w"), _opt(bias, x.dtype, "bias"), _opt(residual, x.dtype, "residual"),
+          _dev(out, None, "out"), _code(x, "x"), M, K, N, _stream())
+    return out
+
+
+def conv3x3_ok(B, H, W, Cin, N):
+    M = B * H * W
+    return (Cin % 64 == 0 and N % 8 == 0 and M * Cin * 2 < 2 ** 31 - 16 and N * 9 * Cin * 2 < 2 ** 31 - 16
+            and -(-M // GEMM_BM) * -(-N // (2 * GEMM_BN)) >= GEMM_MIN_BLOCKS)
+
+
+def conv3x3_nhwc(x, w, bias=None, sample_bias=None, residual=None):
+    """x [B,Cin,H,W] and w [N,Cin,3,3] in torch.channels_last memory format (16-bit) -> conv2d(x, w, stride 1, padding 1)
+    + bias[n] + sample_bias[b, n] + residual, channels_last.  See ed_conv3x3_nhwc."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)):
+        _reject("conv3x3_nhwc: x must be a 16-bit [B,C,H,W] tensor on the MI355X; no CPU fallback")
+    B, Cin, H, W = x.shape
+    N = w.shape[0]
+    cl = torch.channels_last
+    if tuple(w.shape) != (N, Cin, 3, 3) or w.dtype != x.dtype or not conv3x3_ok(B, H, W, Cin, N):
+        _reject(f"conv3x3_nhwc: unsupported shape x {tuple(x.shape)} w {tuple(w.shape)}")
+    if not x.is_contiguous(memory_format=cl) or not w.is_contiguous(memory_format=cl):
+        _reject("conv3x3_nhwc: x and w must be channels_last")
+    out = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+    if residual is not None and (residual.shape != out.shape or residual.dtype != x.dtype or not residual.is_contiguous(memory_format=cl)):
+        _reject("conv3x3_nhwc: residual must be a channels_last tensor of the output's shape")
+    if sample_bias is not None and tuple(sample_bias.shape) != (B, N):
+        _reject("conv3x3_nhwc: sample_bias must be [B, N]")
+    TIMER.note_work("ed_conv3x3_nhwc", flops=2.0 * B * H * W * 9 * Cin * N,
+                    nbytes=2.0 * (B * H * W * (Cin + N * (2 if residual is not None else 1)) + 9 * Cin * N))
+    _call("ed_conv3x3_nhwc", x.data_ptr(), w.data_ptr(), _opt(bias, x.dtype, "bias"), _opt(sample_bias, x.dtype, "sample_bias"),
+          None if residual is None else residual.data_ptr(), out.data_ptr(), _code(x, "x"), B, H, W, Cin, N, _stream_of(x))
+    return out
+
+
 GROUPNORM_SPLIT = True  # large groups: statistics + apply as two fully parallel launches (A/B switch)
 
 

@@ -325,6 +325,38 @@ int ed_groupnorm_f32(const void* x, const void* gamma, const void* beta, void* o
  */
 int ed_softmax_rows(void* x, int64_t rows, int64_t cols, float scale, void* stream);
 
+/*
+ * ---- dense contractions inside the UNet (csrc/gemm_kernels.hip): one 256 x 256 x 64, 8-wave, 8-phase MFMA main loop
+ * (LDS-DMA staging with counted vmcnt, st_16x32-swizzled LDS image) behind three entry points.  16-bit I/O, fp32
+ * accumulation, ONE rounding of the epilogue's fp32 result.  All pointers 16-byte aligned; byte sizes of x and w below
+ * 2^31 (32-bit buffer offsets); hipErrorInvalidValue for a shape outside these limits (the caller keeps the library call).
+ *
+ * ed_geglu_gemm -- diffusers GEGLU.forward (`h, gate = proj(x).chunk(2, -1); h * gelu(gate)`) in one kernel:
+ *   out[m, n] = (x[m,:] . w[n,:] + bias[n]) * gelu(x[m,:] . w[I+n,:] + bias[I+n])
+ *   x [M, K], w [2I, K] (torch Linear weight), bias [2I] or NULL, out [M, I]; K % 64 == 0, I % 128 == 0.
+ *   gelu = x Phi(x) with erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7), evaluated on the fp32 accumulator: the
+ *   projection output is never rounded to 16 bits and never touches HBM.
+ */
+int ed_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I, void* stream);
+
+/*
+ * ed_linear -- torch.nn.functional.linear with an optional fused residual: out = x w^T + bias (+ residual)
+ *   x [M, K], w [N, K], bias [N] or NULL, residual [M, N] or NULL, out [M, N]; K % 64 == 0, N % 8 == 0.
+ */
+int ed_linear(const void* x, const void* w, const void* bias, const void* residual, void* out, int dtype, int64_t M, int K, int N,
+              void* stream);
+
+/*
+ * ed_conv3x3_nhwc -- Conv2d(Cin, N, 3, stride 1, padding 1) on a channels-last image as an implicit GEMM (K = 9 Cin; the A
+ * operand row of output pixel m at tap (dy, dx) is the Cin vector of pixel m + dy W + dx, zeros outside the image), with
+ * ResnetBlock2D's adds in the epilogue:
+ *   out[b,y,x,n] = sum_{dy,dx,c} x[b,y+dy,x+dx,c] w[n,dy,dx,c] + bias[n] + sample_bias[b,n] + residual[b,y,x,n]
+ *   x [B,H,W,Cin], w [N,3,3,Cin] (a torch Conv2d weight in channels_last memory format), bias [N] / sample_bias [B,N] /
+ *   residual [B,H,W,N] or NULL, out [B,H,W,N]; Cin % 64 == 0, N % 8 == 0.
+ */
+int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* sample_bias, const void* residual, void* out,
+                    int dtype, int B, int H, int W, int Cin, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

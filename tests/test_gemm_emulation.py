@@ -1,5 +1,6 @@
-"""CPU: the not-yet-validated kernels under experiments/ keep compiling for gfx950 and keep passing their CPU replays.
-Nothing here (or anywhere in the product) launches them; see experiments/README.md."""
+"""CPU: the 8-phase GEMM kernel (csrc/gemm_kernels.hip) keeps compiling for gfx950 within its register / LDS budget, and its
+lane-level CPU replay (tools/emulate_gemm_kernel.py: every address, the LDS-DMA / fragment-read hazard intervals under the two
+adversarial timings) stays exact -- the check that let the kernel run correctly on its first GPU launch."""
 import os
 import re
 import shutil
@@ -9,11 +10,10 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXP = os.path.join(ROOT, "experiments", "geglu_gemm")
 
 
-def test_geglu_gemm_replay_is_exact_and_catches_broken_schedules():
-    run = lambda *a: subprocess.run([sys.executable, os.path.join(EXP, "emulate_geglu_gemm.py"), "--quick", *a],
+def test_gemm_kernel_replay_is_exact_and_catches_broken_schedules():
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_gemm_kernel.py"), "--quick", *a],
                                     capture_output=True, text=True, cwd=ROOT)
     ok = run()
     assert ok.returncode == 0 and "WRONG" not in ok.stdout, ok.stdout + ok.stderr
@@ -23,13 +23,13 @@ def test_geglu_gemm_replay_is_exact_and_catches_broken_schedules():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
-def test_geglu_gemm_compiles_for_gfx950_without_spills(tmp_path):
-    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                          os.path.join(EXP, "geglu_gemm.hip"), "-o", str(tmp_path / "libgeglu_gemm.so"),
+def test_gemm_kernels_compile_for_gfx950_without_spills(tmp_path):
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-c",
+                          os.path.join(ROOT, "elasticdiffusion_official_amd", "csrc", "gemm_kernels.hip"), "-o", str(tmp_path / "gemm.o"),
                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
     rep = out.stderr
-    assert len(re.findall(r"Function Name: .*k_geglu_gemm", rep)) == 12         # bf16 / f16 x GEGLU / plain / 3x3 convolution x (normal, SAFE diagnosis build)
+    assert len(re.findall(r"Function Name: .*k_gemm_8phase", rep)) == 6         # bf16 / f16 x GEGLU / plain / 3x3 convolution
     assert set(re.findall(r"VGPRs Spill: (\d+)", rep)) == {"0"} and set(re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", rep)) == {"0"}
     assert all(int(v) <= 256 for v in re.findall(r" VGPRs: (\d+)", rep))         # 2 waves per SIMD
     assert set(re.findall(r"LDS Size \[bytes/block\]: (\d+)", rep)) == {"131072"}

@@ -514,3 +514,111 @@ def test_fp32_vae_uses_hip_groupnorm_and_matches_torch():
         M.VAE_HIP_GROUPNORM, M.VAE_HIP_ATTENTION = saved
     for a, b in ((enc, enc0), (dec, dec0)):
         assert float((a - b).norm() / b.norm()) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: the 8-phase MFMA main loop behind ed_geglu_gemm / ed_linear / ed_conv3x3_nhwc (csrc/gemm_kernels.hip)
+# ---------------------------------------------------------------------------------------------------
+def _asym(shape, g, scale=1.0):
+    """uniform [-1, 1) data: asymmetric by construction, so a transposed operand or store cannot pass"""
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.fixture
+def any_grid(monkeypatch):
+    """the wrappers refuse grids too small to fill the chip (the model then keeps the library call); tests want every shape"""
+    from elasticdiffusion_official_amd import ops
+    monkeypatch.setattr(ops, "GEMM_MIN_BLOCKS", 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,I", [(256, 64, 128), (300, 192, 256), (1000, 320, 1280), (4099, 640, 2560), (2048, 1280, 5120), (1, 64, 128)])
+def test_geglu_gemm(dtype, M, K, I, any_grid):
+    """ed_geglu_gemm vs the fp32 reference of GEGLU.forward on the same 16-bit inputs: ragged M, one K tile, odd tile counts,
+    the SDXL shapes' K / I; at least as accurate as the pair it replaces (16-bit projection output + ed_geglu), and 8 launches
+    bit-identical (no atomics, no split-K: any difference between launches would be an LDS race)."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = _asym((M, K), g).to(DEV, dtype)
+    w = _asym((2 * I, K), g, K ** -0.5).to(DEV, dtype)
+    b = _asym((2 * I,), g).to(DEV, dtype)
+    got = ops.geglu_gemm(x, w, b)
+    y = x.float() @ w.float().t() + b.float()
+    ref = y[:, :I] * F.gelu(y[:, I:])
+    unfused = ops.geglu(F.linear(x, w, b), I) if I % 8 == 0 else None
+    rel = float((got.float() - ref).norm() / ref.norm())
+    rel_unfused = float((unfused.float() - ref).norm() / ref.norm())
+    assert got.shape == (M, I) and bool(torch.isfinite(got).all())
+    assert rel < 1.1 * rel_unfused + 1e-5, (rel, rel_unfused)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 2e-5).all())   # one rounding of an fp32 result
+    for _ in range(8):
+        assert torch.equal(ops.geglu_gemm(x, w, b), got)
+    assert torch.equal(ops.geglu_gemm(x.view(1, M, K), w, b).view(M, I), got)
+    nob = ops.geglu_gemm(x, w, None)
+    y0 = x.float() @ w.float().t()
+    assert float((nob.float() - y0[:, :I] * F.gelu(y0[:, I:])).abs().max()) < 8 * ulp
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N", [(256, 64, 256), (300, 128, 200), (1000, 640, 1920), (4099, 640, 640), (2000, 2560, 640), (513, 320, 8)])
+def test_linear_hip(dtype, M, K, N, any_grid):
+    """ed_linear (+bias, +residual) vs fp32: a single rounding of the fp32 result; ragged M and ragged / partial column blocks."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = _asym((M, K), g).to(DEV, dtype)
+    w = _asym((N, K), g, K ** -0.5).to(DEV, dtype)
+    b = _asym((N,), g).to(DEV, dtype)
+    r = _asym((M, N), g).to(DEV, dtype)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    acc = x.float() @ w.float().t()
+    for bias, res in ((b, None), (None, None), (b, r), (None, r)):
+        ref = acc + (0 if bias is None else bias.float()) + (0 if res is None else res.float())
+        got = ops.linear(x, w, bias, res)
+        assert got.shape == (M, N)
+        # fp32 summation order differs from torch's matmul: allow the accumulation noise on top of the single rounding
+        assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all()), float((got.float() - ref).abs().max())
+        for _ in range(4):
+            assert torch.equal(ops.linear(x, w, bias, res), got)
+    lib = F.linear(x, w, b)
+    ref = acc + b.float()
+    assert float((ops.linear(x, w, b).float() - ref).norm()) <= 1.05 * float((lib.float() - ref).norm()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 12, 20, 64, 200), (3, 16, 16, 128, 320), (1, 32, 32, 320, 320), (2, 8, 8, 1280, 640), (5, 7, 9, 192, 72)])
+def test_conv3x3_nhwc(dtype, B, H, W, Cin, N, any_grid):
+    """ed_conv3x3_nhwc vs F.conv2d in fp32 (+ bias, + per-sample channel bias, + residual): image borders, batch seams inside a
+    256-row tile (B H W not a multiple of 256), 1..20 K tiles per tap, partial column blocks; bit-identical over launches."""
+    from elasticdiffusion_official_amd import ops
+    cl = torch.channels_last
+    g = torch.Generator().manual_seed(B * H + Cin)
+    x = _asym((B, Cin, H, W), g).to(DEV, dtype).contiguous(memory_format=cl)
+    w = _asym((N, Cin, 3, 3), g, (9 * Cin) ** -0.5).to(DEV, dtype).contiguous(memory_format=cl)
+    b = _asym((N,), g).to(DEV, dtype)
+    sb = _asym((B, N), g).to(DEV, dtype)
+    r = _asym((B, N, H, W), g).to(DEV, dtype).contiguous(memory_format=cl)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    acc = F.conv2d(x.float(), w.float(), None, padding=1)
+    for bias, sbias, res in ((b, None, None), (None, None, None), (b, sb, None), (b, None, r), (b, sb, r)):
+        ref = acc + (0 if bias is None else bias.float()[None, :, None, None]) + (0 if sbias is None else sbias.float()[:, :, None, None]) \
+            + (0 if res is None else res.float())
+        got = ops.conv3x3_nhwc(x, w, bias, sbias, res)
+        assert got.shape == (B, N, H, W) and got.is_contiguous(memory_format=cl)
+        assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all()), float((got.float() - ref).abs().max())
+        for _ in range(4):
+            assert torch.equal(ops.conv3x3_nhwc(x, w, bias, sbias, res), got)
+
+
+def test_gemm_wrappers_refuse_what_the_kernel_does_not_take():
+    from elasticdiffusion_official_amd import ops
+    x = torch.zeros(512, 96, device=DEV, dtype=torch.float16)       # K % 64 != 0
+    w = torch.zeros(256, 96, device=DEV, dtype=torch.float16)
+    with pytest.raises(RuntimeError):
+        ops.geglu_gemm(x, w)
+    with pytest.raises(RuntimeError):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(512, 128), torch.zeros(256, 128))   # CPU tensors: no CPU fallback
+    assert not ops.linear_wins(20480, 1280, 3840) and ops.linear_wins(81920, 640, 1920) and ops.linear_wins(81920, 2560, 640)
+    assert not ops.conv3x3_ok(20, 128, 128, 4, 320) and ops.conv3x3_ok(20, 32, 32, 1280, 1280) and not ops.conv3x3_ok(1, 8, 8, 1280, 1280)

@@ -1,4 +1,4 @@
-"""Lane-level replay of experiments/geglu_gemm/geglu_gemm.hip on the CPU (numpy): index algebra AND schedule hazards.
+"""Lane-level replay of elasticdiffusion_official_amd/csrc/gemm_kernels.hip on the CPU (numpy): index algebra AND schedule hazards.
 
 The kernel was written with no GPU at hand, so everything that can be checked without one is checked here:
 
@@ -18,7 +18,7 @@ The kernel was written with no GPU at hand, so everything that can be checked wi
   A schedule that gives the exact result under both is free of LDS races between barrier intervals, whatever the DMA
   latency.  (`--break war|raw|lgkm` moves one staging step / weakens one wait / drops the early lgkmcnt and shows the replay catching it.)
 
-Run:  python experiments/geglu_gemm/emulate_geglu_gemm.py            (about a minute)
+Run:  python tools/emulate_gemm_kernel.py            (about a minute)
 """
 import argparse
 import math
