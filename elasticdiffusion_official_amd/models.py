@@ -140,7 +140,7 @@ def _hip_conv3x3(x, conv):
         return False
     from . import ops
     B, C, H, W = x.shape
-    return ops.conv3x3_ok(B, H, W, C, w.shape[0])
+    return ops.conv3x3_wins(B, H, W, C, w.shape[0])
 
 
 def layer_norm(norm, x):

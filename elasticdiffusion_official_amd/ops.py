@@ -332,6 +332,18 @@ def geglu(x2, inner):
 # ---- dense contractions (csrc/gemm_kernels.hip) ---------------------------------------------------------------------
 GEMM_BM, GEMM_BN = 256, 128   # rows / value columns of one workgroup tile (256 output columns for the plain epilogue)
 GEMM_MIN_BLOCKS = 96          # below this many workgroups the 256-CU chip is mostly idle: the library call stays
+GEMM_CUS = 256                # one 128-KiB-LDS workgroup per CU: the grid runs in rounds of 256 tiles
+GEMM_MIN_ROUND_FILL = 0.7     # a multi-round grid whose rounds are on average emptier than this loses to the library's stream-K
+
+
+def _gemm_grid_ok(blocks):
+    """Is a grid of ``blocks`` 256 x 256 tiles worth launching?  Measured (profiles/r4_s2_probe_gemm_*.jsonl): 25 tiles lose
+    2.4 x, 100-120 tiles win 1.06-1.18 x (the library under-fills the chip as well), 288 tiles = 2 rounds, the second 12 %
+    full, lose 0.83-0.90 x; 400 tiles (78 %) and everything fuller win."""
+    if blocks < GEMM_MIN_BLOCKS:
+        return False
+    rounds = -(-blocks // GEMM_CUS)
+    return rounds == 1 or blocks / (rounds * GEMM_CUS) >= GEMM_MIN_ROUND_FILL
 
 
 def _gemm_x(x, name):
@@ -361,14 +373,17 @@ def geglu_gemm(x, w, bias=None):
 
 
 def linear_ok(M, K, N):
-    return (K % 64 == 0 and K >= 64 and N % 8 == 0 and M * K * 2 < 2 ** 31 - 16 and N * K * 2 < 2 ** 31 - 16
-            and -(-M // GEMM_BM) * -(-N // (2 * GEMM_BN)) >= GEMM_MIN_BLOCKS)
+    """what the kernel takes (linear_wins: where the model uses it)"""
+    return K % 64 == 0 and K >= 64 and N % 8 == 0 and M * K * 2 < 2 ** 31 - 16 and N * K * 2 < 2 ** 31 - 16
 
 
 def linear_wins(M, K, N):
-    """Where ed_linear measured faster than hipBLASLt on the MI355X in fp16 (profiles/r4_s1_gemm_first_run_fp16.json: all
-    K = 640 projections 1.1-1.7 x, K = 2560 -> 640 1.12 x; the K = 1280 / 5120 projections 0.91-0.95 x: hipBLASLt stays)."""
-    return linear_ok(M, K, N) and (K <= 640 or (K >= 2560 and N <= 640))
+    """Where ed_linear measured faster than hipBLASLt on the MI355X in fp16, over every projection shape of the SDXL (batch 20
+    and 6) and SD1.5 (batch 20) forwards (profiles/r4_s2_probe_gemm_*.jsonl): hipBLASLt is weak when K <= 640 or N <= 640
+    (388-900 TFLOP/s; this kernel 1.09-1.58 x) and strong on the K >= 1280, N >= 1280 projections (930-1320 TFLOP/s; this
+    kernel 0.70-0.95 x there), whenever the grid fills the chip (_gemm_grid_ok)."""
+    return (linear_ok(M, K, N) and (K <= 640 or N <= 640)
+            and _gemm_grid_ok(-(-M // GEMM_BM) * -(-N // (2 * GEMM_BN))))
 
 
 def linear(x, w, bias=None, residual=None):
@@ -387,9 +402,16 @@ def linear(x, w, bias=None, residual=None):
 
 
 def conv3x3_ok(B, H, W, Cin, N):
+    """what the kernel takes (conv3x3_wins: where the model uses it)"""
     M = B * H * W
-    return (Cin % 64 == 0 and N % 8 == 0 and M * Cin * 2 < 2 ** 31 - 16 and N * 9 * Cin * 2 < 2 ** 31 - 16
-            and -(-M // GEMM_BM) * -(-N // (2 * GEMM_BN)) >= GEMM_MIN_BLOCKS)
+    return Cin % 64 == 0 and N % 8 == 0 and M * Cin * 2 < 2 ** 31 - 16 and N * 9 * Cin * 2 < 2 ** 31 - 16
+
+
+def conv3x3_wins(B, H, W, Cin, N):
+    """Where ed_conv3x3_nhwc measured faster than MIOpen's CK kernels (fp16, profiles/r4_s2_probe_gemm_*.jsonl): every
+    ResnetBlock / upsampler shape whose grid fills the chip -- 1.10-1.59 x at batch 20, 1.06-1.49 x at batch 6 except the
+    288-tile 64 x 64 x 640 shapes (0.83-0.90 x: two rounds, the second 12 % full), 0.4 x on SD1.5's 25-tile 8 x 8 level."""
+    return conv3x3_ok(B, H, W, Cin, N) and _gemm_grid_ok(-(-(B * H * W) // GEMM_BM) * -(-N // (2 * GEMM_BN)))
 
 
 def conv3x3_nhwc(x, w, bias=None, sample_bias=None, residual=None):
@@ -568,7 +590,12 @@ def vae_attention(q, k, v):
 # into the query projection weights -- and the reference maximum rides in the MFMA accumulator's initial value, so a
 # numerator is one v_exp_f32: 157 instead of 189 (lazy) / 214 (exact) instructions per 64-key tile and wave).
 FLASH_V_PATH = None
-FLASH_EXP2 = True   # self-attention through v_path 6 where the pipelined kernel applies (see flash_prescale)
+# Measured inside the SDXL UNet forward on the MI355X (profiles/r4_s2_unet_forward_ab.txt, batch 20 / 6, all other kernels
+# equal): v_path 4 155.2 / 56.5 ms, v_path 5 154.0 / 56.0 ms, v_path 6 155.3 / 56.4 ms.  Removing 12 % (5) and a further 17 % (6)
+# of the loop's instructions moves the forward by < 1 %: the kernel is NOT instruction-issue-bound as round 3 concluded from
+# SQ_ACTIVE_INST_ANY -- every wave re-reads the whole K and V tile from LDS for its 32 query rows (16 KiB per 16 MFMAs), which
+# no variant changes.  5 is the default; 6 stays selectable (FLASH_EXP2 / ED_FLASH_VARIANT=6) and tested.
+FLASH_EXP2 = False   # self-attention through v_path 6 where the pipelined kernel applies (see flash_prescale)
 _ENV_VARIANT = __import__("os").environ.get("ED_FLASH_VARIANT")  # A/B: "legacy" = the round-2 choice, or a variant number
 LOG2E = 1.4426950408889634
 
@@ -614,7 +641,7 @@ def _flash_variant(B, heads, Nq, Nk, k=None, v=None, prescaled=False):
     return legacy
 
 
-FLASH_DEFAULT_PIPE = 4   # pipelined variant for natural-domain q (4 exact / 5 lazy maximum)
+FLASH_DEFAULT_PIPE = 5   # pipelined variant for natural-domain q (4 exact / 5 lazy maximum: +0.4-0.8 % on the forward, profiles/r4_s1_attention_variant_in_unet.txt)
 
 
 def flash_attention(q, k, v, heads, v_path=None, prescaled=False):

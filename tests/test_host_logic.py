@@ -251,13 +251,13 @@ def test_flash_variant_heuristic():
     assert ops._flash_variant(20, 10, 4096, 4096, _Strided(), _Strided()) == 2
     # which shapes get exponent-domain queries: self-attention with >= 2 full key tiles and 32-bit addressable K / V
     c = 0.125 * 1.4426950408889634
-    assert ops.flash_prescale(4096, 4096, 3 * 640) == c and ops.flash_prescale(1024, 1024, 1280) == c
-    assert ops.flash_prescale(64, 64, 3 * 1280) is None and ops.flash_prescale(4096, 4096, 2 ** 20) is None
     saved = ops.FLASH_V_PATH, ops.FLASH_EXP2
     try:
-        ops.FLASH_EXP2 = False
+        ops.FLASH_EXP2 = False   # the default: no in-situ gain measured (ops.py)
         assert ops.flash_prescale(4096, 4096, 3 * 640) is None
         ops.FLASH_EXP2 = True
+        assert ops.flash_prescale(4096, 4096, 3 * 640) == c and ops.flash_prescale(1024, 1024, 1280) == c
+        assert ops.flash_prescale(64, 64, 3 * 1280) is None and ops.flash_prescale(4096, 4096, 2 ** 20) is None
         ops.FLASH_V_PATH = 1
         assert ops._flash_variant(20, 10, 4096, 4096) == 1 and ops.flash_prescale(4096, 4096, 3 * 640) is None
         ops.FLASH_V_PATH = 6   # forcing 6 only applies where the caller really pre-scaled q

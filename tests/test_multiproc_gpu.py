@@ -88,7 +88,8 @@ def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
 
 
 @pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "2", "--in-flight", "2"],
-                                   ["--gpus", "4", "--shard-group", "2", "--in-flight", "2", "--all-layouts"]])
+                                   ["--gpus", "4", "--shard-group", "2", "--in-flight", "2", "--all-layouts"],
+                                   ["--gpus", "8"]])   # the driver's largest layout: one 8-way shard group, 4 images in flight
 def test_bench_multi_rank_rehearsal(flags):
     """bench.py's N > 1 control flow end to end (process groups, row sharding, images in flight, the alternative
     layouts measured after the timed region, max-over-ranks timing, rank 0 printing ONE JSON line) with N ranks sharing
@@ -103,7 +104,7 @@ def test_bench_multi_rank_rehearsal(flags):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "bench.py", *flags, "--steps", "2", "--warmup", "1", "--small",
            "--workload", "sd15_512x1024", "--timesteps", "3", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

@@ -266,7 +266,10 @@ def test_flash_attention_strided_inputs_and_outlier_rows():
         kw = dict(v_path=path, prescaled=path == 6)
         piped = ops.flash_attention(qq, k, v, H, **kw)
         assert torch.equal(piped, ops.flash_attention(qq.contiguous(), k.contiguous(), v.contiguous(), H, **kw))
-        assert float((piped.float() - ref).abs().max()) < 3e-2
+        # v_path 6 is judged on the queries it is given (in the model the factor lives in the projection weights; here the
+        # bf16 rounding of q * c alone moves these large scores by several percent)
+        ref_p = _attn_ref(qq, k, v, H, LN2) if path == 6 else ref
+        assert float((piped.float() - ref_p).abs().max()) < 3e-2
         assert float((piped[0, 5, :64].float() - v[0, 600, :64].float()).abs().max()) < 3e-2
         assert float((piped[1, 7].float() - v[1].float().mean(0)).abs().max()) < 2e-2
 
@@ -620,5 +623,8 @@ def test_gemm_wrappers_refuse_what_the_kernel_does_not_take():
         ops.linear(x, w)
     with pytest.raises(RuntimeError):
         ops.linear(torch.zeros(512, 128), torch.zeros(256, 128))   # CPU tensors: no CPU fallback
+    # where the model uses them (measured policy, profiles/r4_s2_probe_gemm_*.jsonl)
     assert not ops.linear_wins(20480, 1280, 3840) and ops.linear_wins(81920, 640, 1920) and ops.linear_wins(81920, 2560, 640)
-    assert not ops.conv3x3_ok(20, 128, 128, 4, 320) and ops.conv3x3_ok(20, 32, 32, 1280, 1280) and not ops.conv3x3_ok(1, 8, 8, 1280, 1280)
+    assert not ops.linear_wins(24576, 640, 640) and ops.linear_wins(24576, 640, 1920)      # 288 tiles: 2 rounds, 56 % full
+    assert not ops.conv3x3_ok(20, 128, 128, 4, 320) and ops.conv3x3_wins(20, 32, 32, 1280, 1280) and ops.conv3x3_wins(6, 32, 32, 1280, 1280)
+    assert not ops.conv3x3_wins(6, 64, 64, 640, 640) and not ops.conv3x3_wins(20, 8, 8, 1280, 1280) and ops.conv3x3_ok(20, 8, 8, 1280, 1280)
