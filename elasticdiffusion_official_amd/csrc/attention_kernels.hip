@@ -527,7 +527,12 @@ __device__ __forceinline__ void resoftmax_tile(const uint16_t* kt, int ln, int h
 // each followed by one slice of the softmax of S_cur; the A operand of MFMA i+1 is fetched from LDS before MFMA i is
 // issued.  sched_barrier(0) pins that order (left to itself the scheduler clusters all MFMAs ahead of the softmax).
 // EXP2: the two S chains start from `negm` (16 registers, every one = -mb of the lane's query row) instead of zeros.
-template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY, bool EXP2>
+// DEPTH = how many MFMAs ahead an A operand is fetched from LDS.  Round 3 used 1: the ISA shows `ds_read` -> a few VALU ->
+// `s_waitcnt lgkmcnt` -> MFMA with one MFMA slot (~32-40 cycles) between a read and its use, against ~64-100+ cycles of LDS
+// latency for a 16-byte read under load -- every MFMA waits for its operand, which is what holds SQ_VALU_MFMA_BUSY at 0.41
+// whatever the VALU count (v_path 4 / 5 / 6 within 1 % of each other inside the UNet).  DEPTH 3 keeps three reads in flight
+// (+8 VGPRs for the ring).
+template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY, bool EXP2, int DEPTH>
 __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16_t* v_prev, int lane, int ln, int hi,
                                             const typename T::v8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
                                             const typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4],
@@ -542,12 +547,17 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_next[0][i] = s_next[1][i] = 0.f;
   }
-  Vec16 a_cur = {{0u, 0u, 0u, 0u}}, a_nxt = {{0u, 0u, 0u, 0u}};
-  if (N > 0) a_cur = fetch(0);
+  Vec16 ring[DEPTH + 1];   // statically indexed (the loop is fully unrolled): fragment i lives in ring[i % (DEPTH + 1)]
+#pragma unroll
+  for (int r = 0; r <= DEPTH; ++r) ring[r] = Vec16{{0u, 0u, 0u, 0u}};
+#pragma unroll
+  for (int r = 0; r < DEPTH; ++r)
+    if (r < N) ring[r] = fetch(r);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     if (i < N) {
-      if (i + 1 < N) a_nxt = fetch(i + 1);
+      if (i + DEPTH < N) ring[(i + DEPTH) % (DEPTH + 1)] = fetch(i + DEPTH);
+      const Vec16 a_cur = ring[i % (DEPTH + 1)];
       if (i < NQK) {
         if (EXP2 && i < 2) s_next[i & 1] = T::mfma(as_v8<typename T::v8>(a_cur), qf[0], negm);
         else s_next[i & 1] = T::mfma(as_v8<typename T::v8>(a_cur), qf[i >> 1], s_next[i & 1]);
@@ -560,12 +570,11 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
     }
     if (LAZY) softmax_slice_lazy<T, EXP2>(i, s_cur, sl, run, p_cur);
     else softmax_slice<T>(i, s_cur, sl, run, p_cur);
-    if (i + 1 < N) a_cur = a_nxt;
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <typename T, bool LAZY, bool EXP2 = false>
+template <typename T, bool LAZY, bool EXP2 = false, int DEPTH = 1>
 __global__ void __launch_bounds__(256, 2)
 k_flash_attn_pipe(const Params p) {
   static_assert(LAZY || !EXP2, "the exponent-domain variant is built on the lazy-maximum loop");
@@ -661,9 +670,9 @@ k_flash_attn_pipe(const Params p) {
     load_v(t + 1);
     // the first tile (no PV yet) takes the exact softmax; EXP2 found its maximum before the loop and is lazy throughout
     constexpr bool lazy = LAZY && (EXP2 || decltype(has_pv)::value);
-    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2>(sm.k[kb_next], sm.v[vb_prev], lane, ln, hi,
-                                                                                   qf, s_cur, s_next, p_prev, p_cur, oacc, sl,
-                                                                                   run, negm);
+    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2, DEPTH>(sm.k[kb_next], sm.v[vb_prev], lane, ln,
+                                                                                          hi, qf, s_cur, s_next, p_prev, p_cur,
+                                                                                          oacc, sl, run, negm);
     if (lazy) {
       run.alpha = 1.0f;
       if (__any(!(run.psum <= RESCALE_SUM_MAX))) {  // (also catches inf / NaN sums)
@@ -914,7 +923,7 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   Params p;
   p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
   hipStream_t st = (hipStream_t)stream;
-  if (v_path == 4 || v_path == 5 || v_path == 6 || v_path == 8) {  // 4 / 5 / 6 = software-pipelined (5: lazy maximum, 6: + exponent-domain q), 8 = small-KV
+  if (v_path == 4 || v_path == 5 || v_path == 6 || v_path == 7 || v_path == 8) {  // 4 / 5 / 6 = software-pipelined (5: lazy maximum, 6: + exponent-domain q), 8 = small-KV
     if (v_path == 8 && Nk > 96) return (int)hipErrorInvalidValue;
     // the pipelined kernel addresses K / V with 32-bit byte offsets from the head's base pointer
     if (v_path != 8 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
@@ -935,6 +944,9 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
     } else if (v_path == 6) {
       if (dtype == ED_BF16) k_flash_attn_pipe<BF, true, true><<<grid, block, 0, st>>>(p);
       else k_flash_attn_pipe<HF, true, true><<<grid, block, 0, st>>>(p);
+    } else if (v_path == 7) {  // 4 with the LDS operand reads three MFMAs ahead
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF, false, false, 3><<<grid, block, 0, st>>>(p);
+      else k_flash_attn_pipe<HF, false, false, 3><<<grid, block, 0, st>>>(p);
     } else if (Nk <= 64) {
       if (dtype == ED_BF16) k_flash_attn_smallkv<BF, 2><<<grid, block, 0, st>>>(p);
       else k_flash_attn_smallkv<HF, 2><<<grid, block, 0, st>>>(p);
