@@ -17,7 +17,12 @@ import torch
 
 
 class GraphedForward:
-    def __init__(self, fwd, enabled=True, warmup_iters=2):
+    def __init__(self, fwd, enabled=True, warmup_iters=2, prepare=None):
+        """``prepare(text, into=None) -> extra`` (optional): values that depend on the side inputs only (the cross-attention
+        k / v of the text rows).  It runs eagerly, OUTSIDE the graph, whenever the side inputs are (re)copied -- once per image
+        with one image in flight -- and the forward receives its result as a last argument; ``into`` = the result of the
+        previous call for this batch shape, to be overwritten in place (the graph reads those tensors at fixed addresses)."""
+        self._prepare_ref = None if prepare is None else (weakref.WeakMethod(prepare) if hasattr(prepare, "__self__") else (lambda: prepare))
         # a bound method would make pipeline <-> runner a reference cycle that only the cyclic GC can free -- and a
         # hipGraph being destroyed by a GC pass that happens to run *during another capture* aborts the process
         self._fwd_ref = weakref.WeakMethod(fwd) if hasattr(fwd, "__self__") else (lambda: fwd)
@@ -32,6 +37,10 @@ class GraphedForward:
         if f is None:
             raise RuntimeError("the pipeline that owns this GraphedForward is gone")
         return f(*a)
+
+    def prepare(self, text, into=None):
+        f = None if self._prepare_ref is None else self._prepare_ref()
+        return None if (f is None or text is None) else f(text, into)
 
     def stats(self):
         """{"captured": shapes replayed as hipGraphs, "eager": shapes whose capture failed (run eagerly), "replays": n}
@@ -67,12 +76,13 @@ class GraphedForward:
         ent["text"] = None if text is None else text.clone()
         ent["pooled"] = None if pooled is None else pooled.clone()
         ent["cond"] = None if cond is None else cond.clone()
+        ent["extra"] = self.prepare(ent["text"])
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):  # warm-up off the capture: MIOpen find / allocator growth happen here
             for _ in range(self.warmup_iters):
-                self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
+                self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"], ent["extra"])
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         # No Python GC pass may run while the stream is capturing: collecting an old pipeline's hipGraph / memory pool
@@ -84,7 +94,7 @@ class GraphedForward:
             # thread_local: the RCCL watchdog thread polls events while we capture; in "global" mode that would
             # invalidate the capture on multi-GPU runs
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                ent["out"] = self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"])
+                ent["out"] = self.fwd(x, ent["t"], ent["text"], ent["pooled"], ent["cond"], ent["extra"])
         finally:
             if gc_was_enabled:
                 gc.enable()
@@ -94,14 +104,14 @@ class GraphedForward:
         """``fresh_side``: the text / pooled / condition rows differ from call to call (fused batches of several images
         in flight), so they are copied into the graph's static buffers on every replay, not once per image."""
         if not self.enabled:
-            return self.fwd(x, t, text, pooled, cond)
+            return self.fwd(x, t, text, pooled, cond, None)
         key = self._key(x.shape, x.dtype, cond, t.shape)
         ent = self.entries.get(key)
         if ent is None:
             ent = {"x": torch.empty_like(x), "graph": None, "epoch": -1, "eager": False}
             self.entries[key] = ent
         if ent["eager"]:
-            return self.fwd(x, t, text, pooled, cond)
+            return self.fwd(x, t, text, pooled, cond, None)
         if x.data_ptr() != ent["x"].data_ptr():
             ent["x"].copy_(x)
         if ent["graph"] is None:
@@ -112,13 +122,15 @@ class GraphedForward:
                               "running this shape eagerly")
                 ent["eager"] = True
                 torch.cuda.synchronize()
-                return self.fwd(x, t, text, pooled, cond)
+                return self.fwd(x, t, text, pooled, cond, None)
             ent["epoch"] = self.epoch
         ent["t"].copy_(t)
         if fresh_side or ent["epoch"] != self.epoch:
             for name, src in (("text", text), ("pooled", pooled), ("cond", cond)):
                 if src is not None:
                     ent[name].copy_(src)
+            if ent.get("extra") is not None:
+                self.prepare(ent["text"], ent["extra"])   # same tensors, new contents
             ent["epoch"] = self.epoch
         ent["graph"].replay()
         self.replays += 1

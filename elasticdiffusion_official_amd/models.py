@@ -274,7 +274,17 @@ class Attention(nn.Module):
             cache[slot] = (key, torch.cat(ws, dim=0).contiguous())
         return cache[slot][1]
 
-    def forward(self, x, context=None):
+    def project_kv(self, context, out=None):
+        """k, v of a cross-attention as ONE [B, Nk, 2 inner] tensor (fused weight).  They depend on the text rows only -- not on
+        the latent, not on the timestep -- so a caller may compute them once per image and hand them to ``forward`` (``kv``)
+        instead of re-projecting the same 77 tokens in every one of the ~100 forwards of an image (UNet.cross_attention_kv)."""
+        w = self._fused_weight(("to_k", "to_v"))
+        if out is None:
+            return F.linear(context, w)
+        torch.matmul(context, w.t(), out=out)
+        return out
+
+    def forward(self, x, context=None, kv=None):
         B, N, _ = x.shape
         inner = self.to_q.out_features
         if (FLASH_ATTENTION and _fusable(x) and inner == self.heads * 64 and self.to_q.bias is None
@@ -293,16 +303,20 @@ class Attention(nn.Module):
                 return linear_(o, self.to_out[0].weight, self.to_out[0].bias)
             else:
                 q = linear_(x, self.to_q.weight)
-                if FUSED_QKV:
-                    kv = F.linear(context, self._fused_weight(("to_k", "to_v")))
+                if kv is not None or FUSED_QKV:
+                    if kv is None:
+                        kv = self.project_kv(context)
                     k, v = kv[..., :inner], kv[..., inner:]
                 else:
                     k, v = self.to_k(context), self.to_v(context)
             return linear_(ops.flash_attention(q, k, v, self.heads), self.to_out[0].weight, self.to_out[0].bias)
         ctx = x if context is None else context
         q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
-        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
-        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+        if kv is not None:
+            k, v = (t.reshape(B, ctx.shape[1], self.heads, -1).transpose(1, 2) for t in (kv[..., :inner], kv[..., inner:]))
+        else:
+            k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
+            v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)
         return self.to_out[0](o.transpose(1, 2).reshape(B, N, -1))
 
@@ -344,15 +358,16 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def forward(self, x, context, pending=None):
+    def forward(self, x, context, pending=None, kv=None):
         """-> (ff_out, x): the block's output is ``ff_out + x``; the caller either hands the pair to the next block
-        (whose norm1 then runs fused with that add) or sums it.  ``pending``: the previous block's ff_out."""
+        (whose norm1 then runs fused with that add) or sums it.  ``pending``: the previous block's ff_out.  ``kv``: dict
+        {id(attention module): precomputed k|v} (UNet.cross_attention_kv) or None."""
         if pending is not None:
             x, h = add_layer_norm(self.norm1, pending, x)                 # x = prev_ff + x ; norm1(x)
         else:
             h = layer_norm(self.norm1, x)
         x, h = add_layer_norm(self.norm2, self.attn1(h), x)               # x = attn1(norm1(x)) + x ; norm2(x)
-        x, h = add_layer_norm(self.norm3, self.attn2(h, context), x)      # x = attn2(norm2(x)) + x ; norm3(x)
+        x, h = add_layer_norm(self.norm3, self.attn2(h, context, None if kv is None else kv.get(id(self.attn2))), x)  # x = attn2(norm2(x)) + x ; norm3(x)
         return self.ff(h), x
 
 
@@ -365,7 +380,7 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, ch // heads, cross_dim) for _ in range(depth)])
         self.proj_out = nn.Linear(ch, ch) if linear_proj else nn.Conv2d(ch, ch, 1)
 
-    def forward(self, x, context):
+    def forward(self, x, context, kv=None):
         B, C, H, W = x.shape
         if self.linear_proj:
             h = linear_(group_norm_act(self.norm, x, tokens=True), self.proj_in.weight, self.proj_in.bias)
@@ -373,7 +388,7 @@ class Transformer2DModel(nn.Module):
             h = self.proj_in(group_norm_act(self.norm, x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
         pend = None
         for blk in self.transformer_blocks:
-            pend, h = blk(h, context, pend)
+            pend, h = blk(h, context, pend, kv)
         h = pend + h
         if self.linear_proj:
             h = linear_(h, self.proj_out.weight, self.proj_out.bias)
@@ -453,12 +468,12 @@ class _DownBlock(nn.Module):
         self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, depth, cross, linear) for _ in range(layers)]) if attn else None
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if downsample else None
 
-    def forward(self, x, temb, ctx):
+    def forward(self, x, temb, ctx, kv=None):
         outs = []
         for i, r in enumerate(self.resnets):
             x = r(x, temb)
             if self.attentions is not None:
-                x = self.attentions[i](x, ctx)
+                x = self.attentions[i](x, ctx, kv)
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0](x)
@@ -472,8 +487,8 @@ class _MidBlock(nn.Module):
         self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb), ResnetBlock2D(ch, ch, temb)])
         self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, depth, cross, linear)])
 
-    def forward(self, x, temb, ctx):
-        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+    def forward(self, x, temb, ctx, kv=None):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx, kv), temb)
 
 
 class _UpBlock(nn.Module):
@@ -487,11 +502,11 @@ class _UpBlock(nn.Module):
         self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, depth, cross, linear) for _ in range(layers)]) if attn else None
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if upsample else None
 
-    def forward(self, x, skips, temb, ctx):
+    def forward(self, x, skips, temb, ctx, kv=None):
         for i, r in enumerate(self.resnets):
             x = r(torch.cat([x, skips.pop()], dim=1), temb)
             if self.attentions is not None:
-                x = self.attentions[i](x, ctx)
+                x = self.attentions[i](x, ctx, kv)
         if self.upsamplers is not None:
             x = self.upsamplers[0](x)
         return x
@@ -546,8 +561,20 @@ class UNet2DConditionModel(nn.Module):
             emb = emb + self.add_embedding(add)
         return emb
 
+    def cross_attention_kv(self, encoder_hidden_states, into=None):
+        """{id(attention module): k|v [B, 77, 2 inner]} for every cross-attention of the model: functions of the text rows only,
+        so the pipeline computes them once per image (per hipGraph batch shape) instead of once per forward -- 70 projections
+        of 77 tokens per SDXL forward, ~100 forwards per image.  ``into``: a dict from an earlier call whose tensors are
+        overwritten in place (a captured hipGraph reads them at fixed addresses)."""
+        ctx = encoder_hidden_states.to(self.dtype)
+        out = {} if into is None else into
+        for m in self.modules():
+            if isinstance(m, BasicTransformerBlock):
+                out[id(m.attn2)] = m.attn2.project_kv(ctx, None if into is None else into[id(m.attn2)])
+        return out
+
     def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None,
-                down_block_additional_residuals=None, mid_block_additional_residual=None, **_):
+                down_block_additional_residuals=None, mid_block_additional_residual=None, cross_kv=None, **_):
         x = sample.to(self.dtype)
         if CHANNELS_LAST and x.is_cuda and x.dtype != torch.float32:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -556,15 +583,15 @@ class UNet2DConditionModel(nn.Module):
         x = self.conv_in(x)
         skips = [x]
         for blk in self.down_blocks:
-            x, outs = blk(x, emb, ctx)
+            x, outs = blk(x, emb, ctx, cross_kv)
             skips.extend(outs)
         if down_block_additional_residuals is not None:
             skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
-        x = self.mid_block(x, emb, ctx)
+        x = self.mid_block(x, emb, ctx, cross_kv)
         if mid_block_additional_residual is not None:
             x = x + mid_block_additional_residual
         for blk in self.up_blocks:
-            x = blk(x, skips, emb, ctx)
+            x = blk(x, skips, emb, ctx, cross_kv)
         x = self.conv_out(group_norm_act(self.conv_norm_out, x, silu=True))
         return ModelOutput(sample=x)
 
@@ -623,9 +650,10 @@ class ControlNetModel(nn.Module):
         return self.conv_in.weight.dtype
 
     embed = UNet2DConditionModel.embed
+    cross_attention_kv = UNet2DConditionModel.cross_attention_kv
 
     def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0,
-                guess_mode=False, return_dict=False, added_cond_kwargs=None, **_):
+                guess_mode=False, return_dict=False, added_cond_kwargs=None, cross_kv=None, **_):
         x = sample.to(self.dtype)
         cond = controlnet_cond.to(self.dtype)
         if CHANNELS_LAST and x.is_cuda and x.dtype != torch.float32:
@@ -636,9 +664,9 @@ class ControlNetModel(nn.Module):
         x = self.conv_in(x) + self.controlnet_cond_embedding(cond)
         skips = [x]
         for blk in self.down_blocks:
-            x, outs = blk(x, emb, ctx)
+            x, outs = blk(x, emb, ctx, cross_kv)
             skips.extend(outs)
-        x = self.mid_block(x, emb, ctx)
+        x = self.mid_block(x, emb, ctx, cross_kv)
         down = [conv(s) * conditioning_scale for conv, s in zip(self.controlnet_down_blocks, skips)]
         mid = self.controlnet_mid_block(x) * conditioning_scale
         return down, mid

@@ -215,7 +215,7 @@ class ElasticDiffusion(nn.Module):
         self.cache_backgrounds = cache_backgrounds
         self._frame_cache = {}
         # one hipGraph per model batch shape (graphs.py); falls back to eager launches if a capture fails
-        self._runner = GraphedForward(self._forward_rows, enabled=use_graphs)
+        self._runner = GraphedForward(self._forward_rows, enabled=use_graphs, prepare=self._text_kv)
         self._time_ids = torch.zeros(1, 6, dtype=torch.float32, device=device)  # persistent: captured by the graphs
         self.set_view_config()
         self.default_size = None
@@ -406,15 +406,34 @@ class ElasticDiffusion(nn.Module):
         return text, pooled
 
     # ---- model boundary ----------------------------------------------------------------------------
-    def _forward_rows(self, x, t_dev, txt, pl, cond):
+    # The cross-attention k / v of the text rows are the same in every forward of an image: computed once per image and batch
+    # shape, outside the hipGraph (models.UNet2DConditionModel.cross_attention_kv; 70 projections per SDXL forward otherwise)
+    TEXT_KV_ONCE = True
+
+    def _text_kv(self, txt, into=None):
+        """GraphedForward's ``prepare``: {"unet": {...}, "controlnet": {...}} of precomputed cross-attention k|v tensors for
+        the text rows ``txt``, or None for models that do not offer it (injected stand-ins) / when switched off."""
+        if not self.TEXT_KV_ONCE or not hasattr(self.unet, "cross_attention_kv"):
+            return None
+        out = {} if into is None else into
+        out["unet"] = self.unet.cross_attention_kv(txt, None if into is None else into["unet"])
+        if self.controlnet is not None and hasattr(self.controlnet, "cross_attention_kv"):
+            out["controlnet"] = self.controlnet.cross_attention_kv(txt, None if into is None else into["controlnet"])
+        return out
+
+    def _forward_rows(self, x, t_dev, txt, pl, cond, text_kv=None):
         """ED:413-426 / EDC:476-518 for an arbitrary batch of d x d rows (this is what a hipGraph captures)."""
-        kw = {}
+        kw, ckw = {}, {}
         if self.sd_version.startswith("XL"):
             ids = self._time_ids.to(txt.dtype).expand(x.shape[0], -1)
             kw["added_cond_kwargs"] = {"text_embeds": pl, "time_ids": ids}
+        if text_kv is not None:
+            kw["cross_kv"] = text_kv["unet"]
+            ckw["cross_kv"] = text_kv.get("controlnet")
         if cond is not None:
+            cn_kw = {k: v for k, v in kw.items() if k != "cross_kv"}
             down, mid = self.controlnet(x, t_dev, encoder_hidden_states=txt, controlnet_cond=cond,
-                                        conditioning_scale=self._cn_scale, guess_mode=False, return_dict=False, **kw)
+                                        conditioning_scale=self._cn_scale, guess_mode=False, return_dict=False, **cn_kw, **ckw)
             kw["down_block_additional_residuals"], kw["mid_block_additional_residual"] = down, mid
         return self.unet(x, t_dev, encoder_hidden_states=txt, **kw)["sample"].contiguous()
 

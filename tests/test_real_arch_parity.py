@@ -13,6 +13,7 @@ Bars:
     random-init UNet under guidance 10 is a property of the dtype; what this repo adds on top of it is what is gated;
 The measured numbers are written to gpurun_out/parity_real_arch.json for DESIGN.md.
 """
+import copy
 import json
 import os
 
@@ -91,3 +92,36 @@ def test_fused_kernels_are_inside_the_bf16_loop():
     glue = {"ed_assemble_rows", "ed_phase_epilogue"} if pipeline.FUSED_GLUE else {"ed_pick_assemble", "ed_gather_views"}
     need = glue | M.fused_unet_entry_points()
     assert need <= seen, sorted(need - seen)
+
+
+def test_text_kv_computed_once_per_image_follows_the_prompt():
+    """pipeline.TEXT_KV_ONCE: the cross-attention k / v of the text rows are computed once per image, outside the hipGraph,
+    into tensors the captured forward reads at fixed addresses.  A second image with ANOTHER prompt through the same pipeline
+    (same graphs) must equal that prompt's image from a fresh pipeline to the 16-bit noise floor -- a stale k / v would give
+    the first prompt's image -- and must match the run with the switch off (k / v re-projected in every forward)."""
+    from elasticdiffusion_official_amd import ElasticDiffusion
+    from tests.fakes import synthetic_text_embeds
+    unet, vae, _ = R.build_small("XL1.0")
+    c = dict(R.REAL_CASES["cfg3_xl_1024x2048"], steps=2, R=1)
+    g = torch.Generator().manual_seed(5)
+    (un, pun), (co, pco) = synthetic_text_embeds(1, cross_dim=64, pooled_dim=32, xl=True)
+    prompts = {"": (un, pun), "a": (co, pco), "b": (co + torch.randn(co.shape, generator=g), pco + torch.randn(pco.shape, generator=g))}
+
+    def make(once):
+        p = ElasticDiffusion("cuda:0", c["sd"], view_batch_size=c["vbs"], unet=copy.deepcopy(unet).to(torch.float16),
+                             vae=copy.deepcopy(vae), text_encoder=lambda s: prompts[s if isinstance(s, str) else s[0]])
+        p.TEXT_KV_ONCE = once
+        return p
+
+    def run(p, prompt):
+        p.seed_everything(c["seed"])
+        return p.generate_latents(prompt, "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
+                                  resampling_steps=c["R"], **R.LOOP_KW).float().cpu()
+
+    pipe = make(True)
+    za, zb = run(pipe, "a"), run(pipe, "b")           # same pipeline, same graphs, the prompt changes in between
+    assert pipe._runner.stats()["eager"] == 0 and pipe._runner.stats()["captured"] >= 1
+    zb_fresh, zb_off = run(make(True), "b"), run(make(False), "b")
+    rel = lambda x, y: float((x - y).norm() / y.norm())   # noqa: E731
+    assert rel(za, zb_fresh) > 0.05, "the two prompts must give different images for this test to mean anything"
+    assert rel(zb, zb_fresh) < 0.03 and rel(zb, zb_off) < 0.03, (rel(zb, zb_fresh), rel(zb, zb_off), rel(za, zb_fresh))

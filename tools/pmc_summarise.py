@@ -27,6 +27,9 @@ ENTRY = {"k_flash_attn_fwd": "ed_flash_attention", "k_flash_attn_pipe": "ed_flas
 
 
 def entry_of(kernel):
+    m = re.search(r"k_gemm_8phase<[^,]*, *(\d), *(true|false)", kernel)   # one main loop, three entry points (EPI, CONV)
+    if m:
+        return "ed_geglu_gemm" if m.group(1) == "0" else ("ed_conv3x3_nhwc" if m.group(2) == "true" else "ed_linear")
     for k, v in ENTRY.items():  # dict order: longer, more specific names come before their prefixes
         if re.search(k + r"(?![a-z])", kernel):
             return v
