@@ -909,6 +909,198 @@ k_flash_attn_smallkv(const Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: any head dimension that is a multiple of 8 up to 160 (SD 1.x: 8 heads of 40 / 80 / 160; SD 2.x: 64).  Round 3's
+// kernels are head_dim 64 only, so the SD1.5 workload (BASELINE.json configs[1]) still went through SDPA -- AOTriton's
+// `attn_fwd`, 25 % of its GPU time (profiles/r4_s5_bench_cfg2_sd15_512x1024_kernel_stats.csv).  Same design as
+// k_flash_attn_fwd (transposed contractions, one query row per lane, P stays in registers, V through the LDS transpose
+// read), with the head dimension padded to DP = a multiple of 32: q's pad columns are zeros in registers, K's pad columns
+// are zeroed once in LDS (0 x garbage could be NaN), V's pad columns produce output rows that are never stored.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+struct GenDims {
+  static constexpr int DP = (DH + 31) / 32 * 32;   // padded head dim: 40 -> 64, 80 -> 96, 160 -> 160
+  static constexpr int NKS = DP / 16;              // 16-wide contraction steps of S^T = K Q^T
+  static constexpr int NDB = DP / 32;              // 32-wide d blocks of O^T = V^T P^T
+  static constexpr int CH = DH / 8;                // 16-byte chunks per K / V row in memory
+  static constexpr int KLD = DP + 8;               // K tile row pitch (elements): 144 / 208 / 336 B -- 16 rows hit 16 distinct bank quads
+  static constexpr int VLD = DP == 64 ? 96 : DP + 16;  // V tile row pitch for ds_read_b64_tr_b16: 4 consecutive rows on distinct banks
+  static constexpr int NLD = (KT * CH + 255) / 256;    // staging chunks per thread and tensor
+};
+
+template <int DH>
+struct SmemGen {
+  uint16_t k[2][KT * GenDims<DH>::KLD];
+  uint16_t v[2][KT * GenDims<DH>::VLD];
+};
+
+// (head dims 40 / 80: <= 256 registers keep S and O in VGPRs, 2 waves per SIMD; 160: 80 accumulator registers for O alone)
+template <typename T, int DH>
+__global__ void __launch_bounds__(256, DH <= 80 ? 2 : 1)
+k_flash_attn_gen(const Params p) {
+  typedef GenDims<DH> G;
+  __shared__ SmemGen<DH> sm;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hi = lane >> 5;
+  int bh, qblk;
+  {
+    const int id = blockIdx.x, per = 8 * p.nqb, grp = id / per, r = id - grp * per;
+    if ((grp + 1) * 8 <= p.BH) {
+      bh = grp * 8 + (r & 7);
+      qblk = r >> 3;
+    } else {
+      bh = grp * 8 + r / p.nqb;
+      qblk = r % p.nqb;
+    }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+  const uint16_t* qg = p.q + b * p.q_sb + h * DH;
+  const uint16_t* kg = p.k + b * p.k_sb + h * DH;
+  const uint16_t* vg = p.v + b * p.v_sb + h * DH;
+  uint16_t* og = p.o + b * p.o_sb + h * DH;
+
+  // Q^T fragments: lane (q = ln, hi) holds d = 16 ks + 8 hi + [0, 8); chunks at d >= DH are zeros
+  const int q_row = qblk * QB + wave * 32 + ln;
+  typename T::v8 qf[G::NKS];
+#pragma unroll
+  for (int ks = 0; ks < G::NKS; ++ks) {
+    const int d0 = 16 * ks + 8 * hi;
+    qf[ks] = as_v8<typename T::v8>(d0 < DH ? load_row16(qg, p.q_sn, q_row, p.Nq, d0) : Vec16{{0u, 0u, 0u, 0u}});
+  }
+  // K pad columns [DH, DP) of both buffers: zero once (the staging below never touches them)
+  if (G::DP > DH) {
+    constexpr int PADC = (G::DP - DH) / 8;
+    for (int idx = tid; idx < 2 * KT * PADC; idx += 256) {
+      const int buf = idx / (KT * PADC), rem = idx - buf * (KT * PADC), row = rem / PADC, c = rem - row * PADC;
+      *reinterpret_cast<Vec16*>(&sm.k[buf][row * G::KLD + DH + 8 * c]) = Vec16{{0u, 0u, 0u, 0u}};
+    }
+  }
+
+  Vec16 kreg[G::NLD], vreg[G::NLD];
+  auto issue_loads = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < G::NLD; ++i) {
+      const int idx = tid + 256 * i, row = idx / G::CH, c = idx - row * G::CH;
+      if (idx < KT * G::CH) {
+        kreg[i] = load_row16(kg, p.k_sn, key0 + row, p.Nk, c * 8);
+        vreg[i] = load_row16(vg, p.v_sn, key0 + row, p.Nk, c * 8);
+      }
+    }
+  };
+  auto write_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < G::NLD; ++i) {
+      const int idx = tid + 256 * i, row = idx / G::CH, c = idx - row * G::CH;
+      if (idx < KT * G::CH) {
+        *reinterpret_cast<Vec16*>(&sm.k[buf][row * G::KLD + c * 8]) = kreg[i];
+        *reinterpret_cast<Vec16*>(&sm.v[buf][row * G::VLD + c * 8]) = vreg[i];
+      }
+    }
+  };
+
+  f32x16 oacc[G::NDB];
+#pragma unroll
+  for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl = p.scale_log2e;
+  const int n_tiles = (p.Nk + KT - 1) / KT;
+
+  issue_loads(0);
+  write_lds(0);
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < n_tiles) issue_loads(t + 1);
+
+    f32x16 s[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const Vec16 kf = *reinterpret_cast<const Vec16*>(&sm.k[buf][(32 * kb + ln) * G::KLD + 16 * ks + 8 * hi]);
+        s[kb] = T::mfma(as_v8<typename T::v8>(kf), qf[ks], s[kb]);
+      }
+    if ((t + 1) * KT > p.Nk) {  // ragged last tile
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KT + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3) >= p.Nk) s[kb][r] = -INFINITY;
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float mb = m_new * sl;
+    const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, sl, -mb));
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl, -mb));
+        s[kb][r] = e;
+        psum += e;
+      }
+    l_run = __builtin_fmaf(l_run, alpha, psum);
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x8 pv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[st >> 1][8 * (st & 1) + j];
+      const typename T::v8 pf = T::pack(pv);
+#pragma unroll
+      for (int db = 0; db < G::NDB; ++db) {
+        const int row = 16 * st + 4 * hi + ((lane & 15) >> 2);
+        const int col = 32 * db + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&sm.v[buf][row * G::VLD + col]));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(&sm.v[buf][(row + 8) * G::VLD + col]));
+        const Vec16 vf = __builtin_bit_cast(Vec16, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        oacc[db] = T::mfma(as_v8<typename T::v8>(vf), pf, oacc[db]);
+      }
+    }
+    if (t + 1 < n_tiles) write_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_row < p.Nq) {
+    uint16_t* orow = og + (int64_t)q_row * p.o_sn;
+#pragma unroll
+    for (int db = 0; db < G::NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * db + 8 * g + 4 * hi;
+        if (d0 < DH) {   // DH % 8 == 0: a group of 4 consecutive d is inside or outside as a whole
+          f32x8 tmp;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tmp[e] = oacc[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
+          const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
+          Vec8 out8 = {{packed.w[0], packed.w[1]}};
+          *reinterpret_cast<Vec8*>(orow + d0) = out8;
+        }
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -917,7 +1109,28 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
                        int head_dim, int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,
                        int64_t o_sb, int64_t o_sn, float scale, int v_path, void* stream) {
   if (B == 0 || H == 0 || Nq == 0) return 0;
-  if (head_dim != D || Nk <= 0) return (int)hipErrorInvalidValue;
+  if (Nk <= 0) return (int)hipErrorInvalidValue;
+  if (head_dim != D) {  // SD 1.x head dimensions: the generic kernel (v_path is ignored)
+    if (head_dim != 40 && head_dim != 80 && head_dim != 160) return (int)hipErrorInvalidValue;
+    if (dtype != ED_BF16 && dtype != ED_F16) return (int)hipErrorInvalidValue;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15u) || ((uintptr_t)out & 7u)) return (int)hipErrorInvalidValue;
+    if ((q_sb | q_sn | k_sb | k_sn | v_sb | v_sn) % 8 || (o_sb | o_sn) % 4) return (int)hipErrorInvalidValue;
+    Params p;
+    p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
+    p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + QB - 1) / QB;
+    p.q_sb = q_sb, p.q_sn = q_sn, p.k_sb = k_sb, p.k_sn = k_sn, p.v_sb = v_sb, p.v_sn = v_sn, p.o_sb = o_sb, p.o_sn = o_sn;
+    p.scale_log2e = scale * 1.44269504088896340736f;
+    const int64_t nb = (int64_t)p.BH * p.nqb;
+    if (nb > 0x7fffffff) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)nb), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define ED_FG(DHV)                                                                      \
+  if (dtype == ED_BF16) k_flash_attn_gen<BF, DHV><<<grid, block, 0, st>>>(p);           \
+  else k_flash_attn_gen<HF, DHV><<<grid, block, 0, st>>>(p);
+    if (head_dim == 40) { ED_FG(40) } else if (head_dim == 80) { ED_FG(80) } else { ED_FG(160) }
+#undef ED_FG
+    return (int)hipGetLastError();
+  }
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15u) || ((uintptr_t)out & 7u)) return (int)hipErrorInvalidValue;
   if ((q_sb | q_sn | k_sb | k_sn | v_sb | v_sn) % 8 || (o_sb | o_sn) % 4) return (int)hipErrorInvalidValue;
   Params p;

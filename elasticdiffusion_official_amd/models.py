@@ -287,12 +287,13 @@ class Attention(nn.Module):
     def forward(self, x, context=None, kv=None):
         B, N, _ = x.shape
         inner = self.to_q.out_features
-        if (FLASH_ATTENTION and _fusable(x) and inner == self.heads * 64 and self.to_q.bias is None
+        if (FLASH_ATTENTION and _fusable(x) and inner % self.heads == 0 and inner // self.heads in (40, 64, 80, 160)
+                and self.to_q.bias is None
                 and (context is None or (_fusable(context) and context.dtype == x.dtype))):
             from . import ops
             if context is None:
                 # exponent-domain kernel: softmax scale * log2 e lives in the query weights (None: natural-domain q)
-                c = ops.flash_prescale(N, N, 3 * inner if FUSED_QKV else inner)
+                c = ops.flash_prescale(N, N, 3 * inner if FUSED_QKV else inner) if inner == self.heads * 64 else None
                 if FUSED_QKV:
                     qkv = linear_(x, self._fused_weight(("to_q", "to_k", "to_v"), c))
                     q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]

@@ -590,6 +590,7 @@ def vae_attention(q, k, v):
 # into the query projection weights -- and the reference maximum rides in the MFMA accumulator's initial value, so a
 # numerator is one v_exp_f32: 157 instead of 189 (lazy) / 214 (exact) instructions per 64-key tile and wave).
 FLASH_V_PATH = None
+FLASH_HEAD_DIMS = (40, 64, 80, 160)   # 64: SDXL / SD 2.x (all the variants above); 40 / 80 / 160: SD 1.x's 8 heads (k_flash_attn_gen)
 # Measured inside the SDXL UNet forward on the MI355X (profiles/r4_s2_unet_forward_ab.txt, batch 20 / 6, all other kernels
 # equal): v_path 4 155.2 / 56.5 ms, v_path 5 154.0 / 56.0 ms, v_path 6 155.3 / 56.4 ms.  Removing 12 % (5) and a further 17 % (6)
 # of the loop's instructions moves the forward by < 1 %: the kernel is NOT instruction-issue-bound as round 3 concluded from
@@ -645,14 +646,17 @@ FLASH_DEFAULT_PIPE = 5   # pipelined variant for natural-domain q (4 exact / 5 l
 
 
 def flash_attention(q, k, v, heads, v_path=None, prescaled=False):
-    """q [B,Nq,H*64], k / v [B,Nk,H*64] 16-bit (last dim contiguous; batch / token strides free, so column slices of a
-    fused QKV projection are fine) -> softmax(q k^T / 8) v as a contiguous [B,Nq,H*64] tensor.  ``prescaled``: q already
+    """q [B,Nq,H*d], k / v [B,Nk,H*d] 16-bit, d = head dim in FLASH_HEAD_DIMS (last dim contiguous; batch / token strides free,
+    so column slices of a fused QKV projection are fine) -> softmax(q k^T / sqrt(d)) v as a contiguous [B,Nq,H*d] tensor.  ``prescaled``: q already
     carries the factor ``flash_prescale`` returned (exponent-domain kernel, v_path 6).  See ed_flash_attention."""
     B, Nq, HD = q.shape
     Nk = k.shape[1]
-    if HD != heads * 64 or k.shape != (B, Nk, HD) or v.shape != (B, Nk, HD):
-        _reject(f"flash_attention: head_dim must be 64 and shapes consistent (q {tuple(q.shape)}, k {tuple(k.shape)}, "
-                f"v {tuple(v.shape)}, heads {heads})")
+    hd = HD // heads
+    if HD != heads * hd or hd not in FLASH_HEAD_DIMS or k.shape != (B, Nk, HD) or v.shape != (B, Nk, HD):
+        _reject(f"flash_attention: head_dim must be one of {FLASH_HEAD_DIMS} and shapes consistent (q {tuple(q.shape)}, "
+                f"k {tuple(k.shape)}, v {tuple(v.shape)}, heads {heads})")
+    if hd != 64 and (prescaled or v_path is not None):
+        _reject("flash_attention: kernel variants exist for head_dim 64 only")
     for t, name in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda or t.dtype != q.dtype or t.stride(2) != 1:
             _reject(f"flash_attention: {name} must be a 16-bit tensor on the MI355X with unit last stride; no CPU fallback")
@@ -664,9 +668,10 @@ def flash_attention(q, k, v, heads, v_path=None, prescaled=False):
         _reject("flash_attention: v_path 6 takes exponent-domain q (prescaled=True) and nothing else does")
     out = torch.empty(B, Nq, HD, dtype=q.dtype, device=q.device)
     # algorithmic work: QK^T and PV contractions (4 B H Nq Nk 64 flop); q, k, v read once, out written once
-    TIMER.note_work("ed_flash_attention", flops=4.0 * B * heads * Nq * Nk * 64,
+    TIMER.note_work("ed_flash_attention", flops=4.0 * B * heads * Nq * Nk * hd,
                     nbytes=2.0 * q.element_size() * HD * B * (Nq + Nk))
+    variant = 0 if hd != 64 else (_flash_variant(B, heads, Nq, Nk, k, v, prescaled) if v_path is None else int(v_path))
     _call("ed_flash_attention", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _code(q, "q"), B, heads, Nq, Nk,
-          64, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
-          0.125, _flash_variant(B, heads, Nq, Nk, k, v, prescaled) if v_path is None else int(v_path), _stream())
+          hd, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+          hd ** -0.5, variant, _stream())
     return out

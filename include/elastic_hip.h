@@ -288,7 +288,8 @@ int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const flo
  *   q   dtype [B, Nq, H, 64]   element strides q_sb (batch), q_sn (token); head stride 64, unit d stride
  *   k,v dtype [B, Nk, H, 64]   strides likewise (q/k/v may be column slices of one fused projection output)
  *   out dtype [B, Nq, H, 64]   strides o_sb, o_sn
- *   head_dim must be 64; dtype = ED_F16 | ED_BF16; q/k/v 16-byte aligned with strides % 8 == 0, out 8-byte aligned
+ *   head_dim = 64 (SDXL, SD 2.x: every v_path below) or 40 / 80 / 160 (SD 1.x's 8 heads: one generic kernel with the head
+ *   dimension zero-padded to a multiple of 32 inside the kernel, v_path ignored); dtype = ED_F16 | ED_BF16; q/k/v 16-byte aligned with strides % 8 == 0, out 8-byte aligned
  *   with strides % 4 == 0.  Nk need not be a multiple of the 64-key tile (cross-attention: 77 text tokens).
  *   v_path: kernel variant.  0 = V transposed on the fly by ds_read_b64_tr_b16, 1 = V^T tile staged in LDS; +2 = 64
  *   query rows per wave (0..3 give bit-identical results).  4 = software-pipelined kernel (softmax of tile t issued in

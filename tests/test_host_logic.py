@@ -327,6 +327,13 @@ def test_flash_attention_index_math_emulation():
         got = emu.run_block(q, k, v, Nq, Nk, 0, 0.125, tr)
         assert sorted(got) == list(range(Nq))
         assert max(np.abs(got[r] - want[r]).max() for r in got) < 1e-12
+    # round 4: the generic-head-dimension kernel (SD 1.x: 40 / 80 / 160), LDS poisoned with NaN before the kernel's own writes
+    for DH in (40, 80, 160):
+        q, k, v = rng.standard_normal((Nq, DH)), rng.standard_normal((Nk, DH)), rng.standard_normal((Nk, DH))
+        want = emu.reference(q, k, v, DH ** -0.5)
+        got = emu.run_block_gen(q, k, v, Nq, Nk, 0, DH ** -0.5, DH)
+        assert sorted(got) == list(range(Nq))
+        assert max(np.abs(got[r] - want[r]).max() for r in got) < 1e-12
 
 
 def test_pipelined_attention_schedule_emulation():

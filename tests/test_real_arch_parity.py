@@ -71,6 +71,31 @@ def test_full_width_sdxl_forward_16bit_error_is_the_dtypes():
         assert r["fused"] <= 1.5 * r["unfused"] + 1e-4, (name, r)
 
 
+def test_full_width_sd15_forward_16bit_error_is_the_dtypes():
+    """The same for the full-width SD 1.5 UNet (BASELINE.json configs[1]): 8 heads of 40 / 80 / 160 -- since round 4 through
+    ed_flash_attention's generic-head-dimension kernel instead of SDPA (AOTriton), plus the GEMM / convolution kernels at
+    SD1.5's shapes."""
+    from elasticdiffusion_official_amd import ops
+    seen = set()
+    orig = ops._call
+
+    def spy(name, *a):
+        seen.add(name)
+        return orig(name, *a)
+
+    ops._call = spy
+    try:
+        rep = R.full_width_forward_report("sd15", batches=(6,))
+    finally:
+        ops._call = orig
+    print(json.dumps(rep))
+    assert "ed_flash_attention" in seen and "ed_geglu_gemm" in seen
+    for name in ("bf16", "fp16"):
+        r = rep[6][name]
+        assert r["fused_finite"] and r["unfused_finite"], r
+        assert r["fused"] <= 1.5 * r["unfused"] + 1e-4, (name, r)
+
+
 def test_fused_kernels_are_inside_the_bf16_loop():
     """The 16-bit run above must actually go through libelastic_hip.so's UNet kernels (not torch fallbacks)."""
     from elasticdiffusion_official_amd import models as M, ops

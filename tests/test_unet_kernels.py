@@ -277,6 +277,33 @@ def test_flash_attention_strided_inputs_and_outlier_rows():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hd", [40, 80, 160])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 8, 4096, 4096), (3, 8, 1024, 1024), (2, 8, 256, 256), (2, 8, 64, 64), (2, 8, 1024, 77), (1, 3, 100, 333), (1, 2, 1, 1)])
+def test_flash_attention_sd1_head_dims(dtype, hd, B, H, Nq, Nk):
+    """ed_flash_attention at SD 1.x's head dimensions (8 heads of 40 / 80 / 160: k_flash_attn_gen, the head dimension
+    zero-padded to a multiple of 32 inside the kernel) vs the fp32 reference; as accurate as SDPA, which it replaces there
+    (AOTriton's attn_fwd was 25 % of the SD1.5 workload's GPU time); q / k / v as column slices of one fused projection."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(hd * 7 + Nk)
+    if Nq == Nk:
+        qkv = torch.randn(B, Nq, 3 * H * hd, device=DEV, generator=g).mul(1.5).to(dtype)
+        q, k, v = qkv[..., :H * hd], qkv[..., H * hd:2 * H * hd], qkv[..., 2 * H * hd:]
+    else:
+        q, k, v = (torch.randn(B, n, H * hd, device=DEV, generator=g).mul(s_).to(dtype) for n, s_ in ((Nq, 1.5), (Nk, 1.5), (Nk, 1.0)))
+    got = ops.flash_attention(q, k, v, H)
+    assert got.shape == (B, Nq, H * hd) and got.is_contiguous() and bool(torch.isfinite(got).all())
+    qf, kf, vf = (t.float().reshape(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, dim=-1) @ vf).transpose(1, 2).reshape(B, Nq, H * hd)
+    sdpa = F.scaled_dot_product_attention(*(t.reshape(B, -1, H, hd).transpose(1, 2) for t in (q, k, v))).transpose(1, 2).reshape(B, Nq, H * hd)
+    err, err_sdpa = float((got.float() - ref).abs().max()), float((sdpa.float() - ref).abs().max())
+    rel, rel_sdpa = float((got.float() - ref).norm() / ref.norm()), float((sdpa.float() - ref).norm() / ref.norm())
+    assert rel < 1.5 * rel_sdpa + 1e-4, (rel, rel_sdpa)
+    assert err < 3.0 * err_sdpa + 4e-3, (err, err_sdpa)
+    with pytest.raises(RuntimeError):
+        ops.flash_attention(q, k, v, H, v_path=4)     # the variants are head_dim 64 only
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Nk", [130, 333, 192, 4096])
 def test_flash_attention_never_reads_past_the_keys(dtype, Nk):
     """the pipelined kernels issue the loads of tiles t+1 / t+2 unconditionally and leave the rows past Nk of

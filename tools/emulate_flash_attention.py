@@ -134,6 +134,105 @@ def run_block(q, k, v, Nq, Nk, qblk, scale, TR):
     return out
 
 
+def gen_dims(DH):
+    """GenDims<DH> of the kernel: (DP, NKS, NDB, CH, KLD, VLD, NLD)."""
+    DP = (DH + 31) // 32 * 32
+    return DP, DP // 16, DP // 32, DH // 8, DP + 8, (96 if DP == 64 else DP + 16), (KT * (DH // 8) + 255) // 256
+
+
+def run_block_gen(q, k, v, Nq, Nk, qblk, scale, DH, poison=np.nan):
+    """k_flash_attn_gen<T, DH> (round 4: SD 1.x head dimensions 40 / 80 / 160): one workgroup of one (batch, head).
+    LDS starts POISONED (NaN) so that a pad column the kernel forgets to zero, or a fragment read outside what was staged,
+    shows up in the result; V's pad columns stay poisoned on purpose (they only feed output rows that are never stored)."""
+    DP, NKS, NDB, CH, KLD, VLD, NLD = gen_dims(DH)
+    out = {}
+    n_tiles = (Nk + KT - 1) // KT
+    k_lds = np.full((2, KT * KLD), poison)
+    v_lds = np.full((2, KT * VLD), poison)
+    if DP > DH:   # the kernel's one-off zeroing of K's pad columns, thread by thread
+        PADC = (DP - DH) // 8
+        for tid in range(256):
+            for idx in range(tid, 2 * KT * PADC, 256):
+                buf, rem = divmod(idx, KT * PADC)
+                row, c = divmod(rem, PADC)
+                k_lds[buf, row * KLD + DH + 8 * c: row * KLD + DH + 8 * c + 8] = 0.0
+
+    def stage(t, buf):   # issue_loads(t) + write_lds(buf) of all 256 threads
+        for tid in range(256):
+            for i in range(NLD):
+                idx = tid + 256 * i
+                if idx < KT * CH:
+                    row, c = divmod(idx, CH)
+                    kr = k[t * KT + row, c * 8:c * 8 + 8] if t * KT + row < Nk else np.zeros(8)
+                    vr = v[t * KT + row, c * 8:c * 8 + 8] if t * KT + row < Nk else np.zeros(8)
+                    k_lds[buf, row * KLD + c * 8: row * KLD + c * 8 + 8] = kr
+                    v_lds[buf, row * VLD + c * 8: row * VLD + c * 8 + 8] = vr
+
+    per_wave = []
+    for wave in range(4):
+        lanes = np.arange(64)
+        ln, hi = lanes & 31, lanes >> 5
+        q_row = qblk * QB + wave * 32 + ln
+        qf = np.zeros((NKS, 64, 8))
+        for ks in range(NKS):
+            for l in range(64):
+                d0 = 16 * ks + 8 * hi[l]
+                if d0 < DH and q_row[l] < Nq:
+                    qf[ks, l] = q[q_row[l], d0:d0 + 8]
+        per_wave.append(dict(lanes=lanes, ln=ln, hi=hi, q_row=q_row, qf=qf, oacc=np.zeros((NDB, 64, 16)),
+                             m=np.full(64, -np.inf), l=np.zeros(64)))
+    sl = scale * np.log2(np.e)
+    stage(0, 0)
+    for t in range(n_tiles):
+        buf = t & 1
+        for w in per_wave:
+            lanes, ln, hi = w["lanes"], w["ln"], w["hi"]
+            s = np.zeros((2, 64, 16))
+            for ks in range(NKS):
+                for kb in range(2):
+                    kf = np.zeros((64, 8))
+                    for l in range(64):
+                        a0 = (32 * kb + ln[l]) * KLD + 16 * ks + 8 * hi[l]
+                        kf[l] = k_lds[buf, a0:a0 + 8]
+                    s[kb] = mfma_32x32x16(kf, w["qf"][ks], s[kb])
+            if (t + 1) * KT > Nk:
+                for kb in range(2):
+                    for r in range(16):
+                        key = t * KT + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3)
+                        s[kb][key >= Nk, r] = -np.inf
+            mx = np.maximum(s[0].max(1), s[1].max(1))
+            mx = np.maximum(mx, mx[lanes ^ 32])
+            m_new = np.maximum(w["m"], mx)
+            alpha = np.exp2(w["m"] * sl - m_new * sl)
+            w["m"] = m_new
+            e = np.exp2(s * sl - (m_new * sl)[None, :, None])
+            w["l"] = w["l"] * alpha + e.sum((0, 2))
+            w["oacc"] *= alpha[None, :, None]
+            for st in range(4):
+                pf = e[st >> 1][:, 8 * (st & 1): 8 * (st & 1) + 8]
+                for db in range(NDB):
+                    row = 16 * st + 4 * hi + ((lanes & 15) >> 2)
+                    col = 32 * db + 16 * ((lanes >> 4) & 1) + 4 * (lanes & 3)
+                    lo = tr_read(v_lds[buf], row * VLD + col)
+                    hi4 = tr_read(v_lds[buf], (row + 8) * VLD + col)
+                    with np.errstate(invalid="ignore"):
+                        w["oacc"][db] = mfma_32x32x16(np.concatenate([lo, hi4], 1), pf, w["oacc"][db])
+        if t + 1 < n_tiles:
+            stage(t + 1, buf ^ 1)
+    for w in per_wave:
+        l_tot = w["l"] + w["l"][w["lanes"] ^ 32]
+        for l in range(64):
+            if w["q_row"][l] < Nq:
+                o = out.setdefault(int(w["q_row"][l]), np.full(DH, np.nan))
+                for db in range(NDB):
+                    for g in range(4):
+                        d0 = 32 * db + 8 * g + 4 * w["hi"][l]
+                        if d0 < DH:
+                            for e_ in range(4):
+                                o[d0 + e_] = w["oacc"][db][l, 4 * g + e_] / l_tot[l]
+    return out
+
+
 def reference(q, k, v, scale):
     s = (q @ k.T) * scale
     p = np.exp(s - s.max(1, keepdims=True))
@@ -154,4 +253,12 @@ if __name__ == "__main__":
                     rows += 1
             print(f"Nq={Nq} Nk={Nk} v_path={'tr' if TR else 'vt'}: rows={rows} max|err|={err:.2e}")
             assert rows == Nq and err < 1e-12
+    for DH in (40, 80, 160):
+        for (Nq, Nk) in [(128, 128), (70, 77), (33, 200)]:
+            q, k, v = rng.standard_normal((Nq, DH)), rng.standard_normal((Nk, DH)), rng.standard_normal((Nk, DH))
+            want = reference(q, k, v, DH ** -0.5)
+            got = run_block_gen(q, k, v, Nq, Nk, 0, DH ** -0.5, DH)
+            err = max(np.abs(got[r] - want[r]).max() for r in got)
+            print(f"head_dim {DH} Nq={Nq} Nk={Nk}: rows={len(got)} max|err|={err:.2e}")
+            assert len(got) == min(Nq, QB) and err < 1e-12
     print("index math OK")
