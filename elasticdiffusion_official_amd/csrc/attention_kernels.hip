@@ -574,11 +574,16 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
   }
 }
 
-template <typename T, bool LAZY, bool EXP2 = false, int DEPTH = 1>
-__global__ void __launch_bounds__(256, 2)
+// WAVES = waves per workgroup (4: 128 query rows, two workgroups per CU; 8: 256 query rows, one workgroup per CU -- the same
+// two waves per SIMD, but every K / V tile is staged ONCE for twice the query rows: half the global loads, LDS writes and L2
+// traffic per MFMA; the ablation of round 4 prices the staging at 17 % of the kernel's time, profiles/r4_s6_attention_ablation.jsonl)
+template <typename T, bool LAZY, bool EXP2 = false, int DEPTH = 1, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, 2)
 k_flash_attn_pipe(const Params p) {
   static_assert(LAZY || !EXP2, "the exponent-domain variant is built on the lazy-maximum loop");
+  static_assert(WAVES == 4 || WAVES == 8, "4 or 8 waves per workgroup");
   constexpr int NK = LAZY ? 3 : 2;
+  constexpr int NST = 8 / WAVES;   // 16-byte chunks of a 64 x 64 tile per thread: 512 chunks over 64 WAVES threads
   __shared__ SmemPipe<NK> sm;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -600,7 +605,7 @@ k_flash_attn_pipe(const Params p) {
   const uint16_t* vg = p.v + b * p.v_sb + h * D;
   uint16_t* og = p.o + b * p.o_sb + h * D;
 
-  const int q_row = qblk * QB + wave * 32 + ln;
+  const int q_row = qblk * (32 * WAVES) + wave * 32 + ln;
   typename T::v8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = as_v8<typename T::v8>(load_row16(qg, p.q_sn, q_row, p.Nq, 16 * ks + 8 * hi));
@@ -613,27 +618,27 @@ k_flash_attn_pipe(const Params p) {
   const int st_row = tid >> 3, st_col = (tid & 7) * 8;
   const uint32_t k_off = (uint32_t)(((int64_t)st_row * p.k_sn + st_col) * 2), k_half = (uint32_t)(32 * p.k_sn * 2);
   const uint32_t v_off = (uint32_t)(((int64_t)st_row * p.v_sn + st_col) * 2), v_half = (uint32_t)(32 * p.v_sn * 2);
-  Vec16 kreg[2], vreg[2];
+  Vec16 kreg[NST], vreg[NST];   // thread's rows: st_row (+ 32 with 4 waves); with 8 waves st_row already spans the 64 rows
   // The whole byte offset goes into the per-lane (VGPR) offset: the hardware range check of a raw buffer load covers
   // VGPR offset + immediate only, a scalar offset is added AFTER it -- a tile offset passed there would let the
   // unconditional loads of tiles past the end, and the rows past Nk of a ragged tile, read whatever follows the tensor.
   auto load_k = [&](int t) {
     const uint32_t base = k_off + (uint32_t)t * 2u * k_half;
-    kreg[0] = buf_load16(k_rs, base, 0);
-    kreg[1] = buf_load16(k_rs, base + k_half, 0);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) kreg[i] = buf_load16(k_rs, base + i * k_half, 0);
   };
   auto load_v = [&](int t) {
     const uint32_t base = v_off + (uint32_t)t * 2u * v_half;
-    vreg[0] = buf_load16(v_rs, base, 0);
-    vreg[1] = buf_load16(v_rs, base + v_half, 0);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) vreg[i] = buf_load16(v_rs, base + i * v_half, 0);
   };
   auto write_k = [&](int buf) {
-    *reinterpret_cast<Vec16*>(&sm.k[buf][st_row * K_LD + st_col]) = kreg[0];
-    *reinterpret_cast<Vec16*>(&sm.k[buf][(st_row + 32) * K_LD + st_col]) = kreg[1];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<Vec16*>(&sm.k[buf][(st_row + 32 * i) * K_LD + st_col]) = kreg[i];
   };
   auto write_v = [&](int buf) {
-    *reinterpret_cast<Vec16*>(&sm.v[buf][st_row * V_LD_TR + st_col]) = vreg[0];
-    *reinterpret_cast<Vec16*>(&sm.v[buf][(st_row + 32) * V_LD_TR + st_col]) = vreg[1];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<Vec16*>(&sm.v[buf][(st_row + 32 * i) * V_LD_TR + st_col]) = vreg[i];
   };
 
   f32x16 oacc[2];
@@ -1136,11 +1141,11 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   Params p;
   p.q = (const uint16_t*)q, p.k = (const uint16_t*)k, p.v = (const uint16_t*)v, p.o = (uint16_t*)out;
   hipStream_t st = (hipStream_t)stream;
-  if (v_path == 4 || v_path == 5 || v_path == 6 || v_path == 7 || v_path == 8) {  // 4 / 5 / 6 = software-pipelined (5: lazy maximum, 6: + exponent-domain q), 8 = small-KV
+  if ((v_path >= 4 && v_path <= 10)) {  // 4 / 5 / 6 = software-pipelined (5: lazy maximum, 6: + exponent-domain q), 8 = small-KV
     if (v_path == 8 && Nk > 96) return (int)hipErrorInvalidValue;
     // the pipelined kernel addresses K / V with 32-bit byte offsets from the head's base pointer
     if (v_path != 8 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
-    const int rows_per_wg = v_path == 8 ? QB * SK_QBLOCKS : QB;
+    const int rows_per_wg = v_path == 8 ? QB * SK_QBLOCKS : (v_path >= 9 ? 2 * QB : QB);
     p.Nq = Nq, p.Nk = Nk, p.H = H, p.BH = B * H, p.nqb = (Nq + rows_per_wg - 1) / rows_per_wg;
     p.q_sb = q_sb, p.q_sn = q_sn, p.k_sb = k_sb, p.k_sn = k_sn, p.v_sb = v_sb, p.v_sn = v_sn, p.o_sb = o_sb, p.o_sn = o_sn;
     p.scale_log2e = scale * 1.44269504088896340736f;
@@ -1160,6 +1165,12 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
     } else if (v_path == 7) {  // 4 with the LDS operand reads three MFMAs ahead
       if (dtype == ED_BF16) k_flash_attn_pipe<BF, false, false, 3><<<grid, block, 0, st>>>(p);
       else k_flash_attn_pipe<HF, false, false, 3><<<grid, block, 0, st>>>(p);
+    } else if (v_path == 9) {  // 4 with 8 waves (256 query rows) per workgroup
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF, false, false, 1, 8><<<grid, dim3(512), 0, st>>>(p);
+      else k_flash_attn_pipe<HF, false, false, 1, 8><<<grid, dim3(512), 0, st>>>(p);
+    } else if (v_path == 10) {  // 5 with 8 waves per workgroup
+      if (dtype == ED_BF16) k_flash_attn_pipe<BF, true, false, 1, 8><<<grid, dim3(512), 0, st>>>(p);
+      else k_flash_attn_pipe<HF, true, false, 1, 8><<<grid, dim3(512), 0, st>>>(p);
     } else if (Nk <= 64) {
       if (dtype == ED_BF16) k_flash_attn_smallkv<BF, 2><<<grid, block, 0, st>>>(p);
       else k_flash_attn_smallkv<HF, 2><<<grid, block, 0, st>>>(p);

@@ -632,7 +632,7 @@ def _flash_variant(B, heads, Nq, Nk, k=None, v=None, prescaled=False):
         return legacy
     if _ENV_VARIANT is not None and int(_ENV_VARIANT) != 6:
         want = int(_ENV_VARIANT)
-        if want in (4, 5, 7):
+        if want in (4, 5, 7, 9, 10):
             return want if (Nk >= 128 and fits) else (8 if Nk <= 96 else legacy)
         return want if (want != 8 or Nk <= 96) else legacy
     if Nk <= 96:

@@ -303,7 +303,8 @@ int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const flo
  *   value of the S accumulators (the MFMA's C operand), so a numerator is one v_exp_f32 of the accumulator: no FMA, no
  *   per-tile maximum (exact maximum of the first tile, then the lazy check of 5).  Same limits as 4 / 5; Nk >= 64.
  *   7 = 4 with every LDS operand read issued three MFMAs ahead of its use instead of one (a 4-deep register ring).
- *   K / V tile loads of 4, 5, 6, 7 carry their whole byte offset in the per-lane offset: rows past Nk read as zeros by the
+ *   9 / 10 = 4 / 5 with 8 waves (256 query rows) per workgroup: each K / V tile is staged once for twice the query rows.
+ *   K / V tile loads of 4 .. 7, 9, 10 carry their whole byte offset in the per-lane offset: rows past Nk read as zeros by the
  *   buffer range check, which does not cover a scalar offset.
  */
 int ed_flash_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,

@@ -215,7 +215,7 @@ def _flash(ops, q, k, v, H, v_path):
     return got, _attn_ref(q, k, v, H, scale), sdpa.transpose(1, 2).reshape(B, Nq, H * 64)
 
 
-@pytest.mark.parametrize("v_path", [0, 1, 2, 3, 4, 5, 6, 7, 8])  # bit 0: V staging; bit 1: 64 rows/wave; 4-7: pipelined; 8: small-KV
+@pytest.mark.parametrize("v_path", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])  # bit 0: V staging; bit 1: 64 rows/wave; 4-7, 9, 10: pipelined; 8: small-KV
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 10, 4096, 4096), (3, 20, 1024, 1024), (2, 20, 1024, 77), (1, 10, 4096, 77),
                                        (2, 2, 256, 256), (1, 4, 64, 64), (1, 1, 100, 77), (2, 3, 200, 333), (1, 2, 1, 1)])
@@ -226,7 +226,7 @@ def test_flash_attention(dtype, B, H, Nq, Nk, v_path):
         pytest.skip("the small-KV kernel takes Nk <= 96")
     if v_path == 6 and Nk < 128:
         pytest.skip("the exponent-domain kernel takes Nk >= 128 (ops.flash_prescale)")
-    if v_path == 7 and Nk < 64:
+    if v_path in (7, 9, 10) and Nk < 64:
         pytest.skip("nothing to pipeline below one full tile")
     g = torch.Generator(device=DEV).manual_seed(Nq * 7 + Nk)
     q, k, v = (torch.randn(B, n, H * 64, device=DEV, generator=g).mul(s).to(dtype) for n, s in ((Nq, 1.5), (Nk, 1.5), (Nk, 1.0)))
@@ -263,7 +263,7 @@ def test_flash_attention_strided_inputs_and_outlier_rows():
         assert torch.equal(again, base)  # strides, the V staging path and the rows-per-wave variant do not change a bit
     # the pipelined kernel (deferred rescale: the outlier row takes the rescale branch in a late tile) on strided and on
     # contiguous inputs: identical to itself, and within the rounding of P of the others
-    for path in (4, 5, 6, 7):
+    for path in (4, 5, 6, 7, 9, 10):
         qq = _exp2_q(q) if path == 6 else q
         kw = dict(v_path=path, prescaled=path == 6)
         piped = ops.flash_attention(qq, k, v, H, **kw)
@@ -320,7 +320,7 @@ def test_flash_attention_never_reads_past_the_keys(dtype, Nk):
     k.copy_(torch.randn(B, Nk, H * 64, device=DEV, generator=g))
     v.copy_(torch.randn(B, Nk, H * 64, device=DEV, generator=g))
     q = torch.randn(B, Nq, H * 64, device=DEV, generator=g).to(dtype)
-    for path in (4, 5, 6, 7, 0):
+    for path in (4, 5, 6, 7, 9, 10, 0):
         got, ref, _ = _flash(ops, q, k, v, H, path)
         assert bool(torch.isfinite(got).all()), path
         assert float((got.float() - ref).abs().max()) < (3e-2 if dtype == torch.bfloat16 else 6e-3), path
@@ -344,7 +344,7 @@ def test_flash_attention_deferred_rescale_branches(dtype):
         kh[0, 64 * tile, 0] = (qh[0, 3, 0].float() * (0.35 * tile * 8.0 / float(qh[0, 3, 0].float().pow(2).sum()))).to(dtype)
     kh[0, 900, 1] = (qh[0, 9, 1].float().sign() * 6.0).to(dtype)   # (b) head 1, query 9: a huge score in tile 14
     kh[0, 5, 1] = (qh[0, 17, 1].float().sign() * 6.0).to(dtype)     # (c) head 1, query 17: the largest score in tile 0
-    for path in (4, 5, 6, 7, 0):
+    for path in (4, 5, 6, 7, 9, 10, 0):
         got, ref, _ = _flash(ops, q, k, v, H, path)
         err = float((got.float() - ref).abs().max())
         assert err < (2e-2 if dtype == torch.bfloat16 else 4e-3), (path, err)
