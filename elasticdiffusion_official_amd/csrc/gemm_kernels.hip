@@ -198,7 +198,14 @@ __device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const Frags<T>& f) {
 }
 
 // the four phases of K tile `tile` (buffer BUFI).  s1: tile + 1 exists, s2: tile + 2 exists (wave-uniform); p1 / p2 their positions.
-template <class T, int BUFI, bool CONV>
+// FIRST ("early start", round 4): K tile 0 of a workgroup whose prologue waited only for what phase 1 reads -- the W value rows
+// and x m-half 0, 4 of its 14 LDS-DMAs per wave -- so the MFMAs start after 32 KiB instead of 64 KiB have landed (a tile's fixed
+// cost is ~7 us against 1.5 us per K tile: 19 % of a K = 1280 tile, 33 % of a K = 640 one).  The gate rows (read in phase 2) and x
+// m-half 1 (phase 3) are retired by a `vmcnt(10)` in front of BOTH barriers of phases 1 and 2: the two wave rows run one barrier
+// apart, so the barrier that publishes a wave's DMAs to the row that reads first is that row's second barrier of the phase and
+// the other row's first one (16 / 18 DMAs issued by then: 10 outstanding = the first 6 / 8 landed).  Replayed under both
+// adversarial timings in tools/emulate_gemm_kernel.py (`--break early` weakens the count and is caught).
+template <class T, int BUFI, bool CONV, bool FIRST = false>
 __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1,
                                             bool s2, KPos p1, KPos p2) {
   // ---- phase 1: m half 0 x value.  12 fragment reads: the 4 W reads first, so that lgkmcnt(8) retires them before the
@@ -208,18 +215,22 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   read_x<T, BUFI>(lds, c, f, 0);
   if (s1) stage_x<BUFI ^ 1, CONV>(lds, c, p1, 1);       // x m-half 1 of tile + 1: its buffer's copy was last read 2 phases ago
   ED_WAIT_LGKM(8);
+  if (FIRST) ED_WAIT_VM(10);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
   __builtin_amdgcn_sched_barrier(0);
   mma16<T, 0, 0>(acc, f);
+  if (FIRST) ED_WAIT_VM(10);
   ED_BARRIER();
   // ---- phase 2: m half 0 x gate
   read_w<T, BUFI, 1>(lds, c, f);
   if (s2) stage_w<BUFI>(lds, c, tile + 2, 0);           // value rows of tile + 2 (read in phase 1, retired before its barrier)
+  if (FIRST) ED_WAIT_VM(10);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
   __builtin_amdgcn_sched_barrier(0);
   mma16<T, 0, 1>(acc, f);
+  if (FIRST) ED_WAIT_VM(10);
   ED_BARRIER();
   // ---- phase 3: m half 1 x gate
   read_x<T, BUFI>(lds, c, f, 1);
@@ -347,11 +358,13 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   stage_x<0, CONV>(lds, c, p0, 0);
   stage_w<0>(lds, c, 0, 1);
   stage_x<0, CONV>(lds, c, p0, 1);
+  const bool early = nt >= 3;     // (every real shape: K >= 320)
   if (nt > 1) {
     stage_w<1>(lds, c, 1, 0);
     stage_x<1, CONV>(lds, c, pa, 0);
     stage_w<1>(lds, c, 1, 1);
-    ED_WAIT_VM(6);
+    if (early) ED_WAIT_VM(10);    // only what phase 1 of tile 0 reads (tile_phases<.., FIRST>)
+    else ED_WAIT_VM(6);
   } else {
     ED_WAIT_VM(0);
   }
@@ -359,6 +372,15 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   if (wrow == 1) ED_BARRIER();    // second wave row runs half a phase behind
 
   int t = 0;
+  if (early) {                    // the first pair of K tiles, tile 0 in its early-start form (s1 = s2 = true: nt >= 3)
+    tile_phases<T, 0, CONV, true>(lds, c, f, acc, 0, true, true, pa, pb);
+    pa = pb;
+    pb = k_next<CONV>(pb, c.cpt);
+    tile_phases<T, 1, CONV>(lds, c, f, acc, 1, true, 3 < nt, pa, pb);
+    pa = pb;
+    pb = k_next<CONV>(pb, c.cpt);
+    t = 2;
+  }
   for (; t + 1 < nt; t += 2) {
     tile_phases<T, 0, CONV>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
     pa = pb;

@@ -81,8 +81,12 @@ class Wave:
 
 
 class Block:
-    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None, epi=0, conv=None):
+    def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None, epi=0, conv=None, row_bias=None, residual=None,
+                 rows_per_sample=1):
         self.x, self.w, self.bias, self.M, self.K, self.I, self.m0, self.n0 = x, w, bias, M, K, I, m0, n0
+        # round 4 epilogue addends of the plain projection / convolution: row_bias [M / rows_per_sample, I] (the time embedding),
+        # residual [M, I]; the kernel reads 8 consecutive columns (16 bytes) per (lane, 16-row block, half) of each
+        self.row_bias, self.residual, self.rows_per_sample = row_bias, residual, rows_per_sample
         self.epi, self.gap = epi, (I if epi == 0 else BN)
         self.conv = conv                                # None, or (img_h, img_w): x is NHWC [B, img_h, img_w, K / 9]
         self.cpt = K // (9 * BK) if conv else 1
@@ -212,9 +216,14 @@ class Block:
                         accv[16 * (i >> 2):16 * (i >> 2) + 16, i & 3] += D[i, :]
 
     # ---- program: a list of barrier-separated segments per wave ------------------------------------------------------
-    def tile_segments(self, wv, bufi, tile, s1, s2):
+    def tile_segments(self, wv, bufi, tile, s1, s2, first=False):
+        """``first`` (round 4, "early start"): tile 0 of a workgroup when the prologue waited only for the operands of phase 1
+        (W value rows + x m-half 0: 4 of its 14 DMAs).  The gate rows (phase 2) and x m-half 1 (phase 3) are then retired by a
+        ``vmcnt(10)`` in front of BOTH barriers of phases 1 and 2: with the two wave rows half a phase apart, the barrier that
+        publishes a wave's DMAs to the row that reads first is that row's second barrier and the other row's first one."""
         brk = self.breakage
         segs = []
+        early = (lambda: self.wait_vm(wv, 12 if brk == "early" else 10)) if first else (lambda: None)
 
         def ph1a():
             self.read_w(wv, bufi, 0)
@@ -225,15 +234,17 @@ class Block:
                 self.stage_x(wv, bufi, tile + 2, 0)    # BROKEN ON PURPOSE: x m-half 0 re-staged in the phase that reads it
             if brk != "lgkm":                           # BROKEN ON PURPOSE without it: value rows re-staged one phase later
                 self.wait_lgkm(wv, 8)
+            early()
         segs.append(ph1a)
-        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 0)))
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 0), early()))
 
         def ph2a():
             self.read_w(wv, bufi, 1)
             if s2:
                 self.stage_w(wv, bufi, tile + 2, 0)
+            early()
         segs.append(ph2a)
-        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 1)))
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 1), early()))
 
         def ph3a():
             self.read_x(wv, bufi, 1)
@@ -265,15 +276,16 @@ class Block:
                 self.stage_w(wv, 1, 1, 0)
                 self.stage_x(wv, 1, 1, 0)
                 self.stage_w(wv, 1, 1, 1)
-                self.wait_vm(wv, 6)
+                self.wait_vm(wv, 10 if early_start else 6)   # early start: only the 4 DMAs phase 1 reads
             else:
                 self.wait_vm(wv, 0)
+        early_start = nt >= 3 and self.breakage != "noearly"
         segs.append(prologue)
         if wv.wrow == 1:
             segs.append(lambda: None)          # the extra barrier of the second wave row
         t = 0
         while t + 1 < nt:
-            segs += self.tile_segments(wv, 0, t, True, t + 2 < nt)
+            segs += self.tile_segments(wv, 0, t, True, t + 2 < nt, first=(t == 0 and early_start))
             segs += self.tile_segments(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
             t += 2
         if t < nt:
@@ -326,10 +338,16 @@ class Block:
                                 out_lin[m[l], self.I + n] = g
                                 out[m[l], n] = np.float32(v) * gelu_as(np.float32(g))
                             else:
-                                if ncol[l] < self.I:
-                                    out_lin[m[l], n] = wv.acc[mb][nf][l, j] + self.bias[n]
-                                if ncol[l] + self.gap < self.I:
-                                    out_lin[m[l], n + self.gap] = wv.acc[mb][2 + nf][l, j] + self.bias[n + self.gap]
+                                for half, ok in ((0, ncol[l] < self.I), (1, ncol[l] + self.gap < self.I)):
+                                    if not ok:       # ok_v / ok_g of the kernel: a whole 8-column group is in or out
+                                        continue
+                                    col = n + half * self.gap
+                                    v = wv.acc[mb][2 * half + nf][l, j] + self.bias[col]
+                                    if self.row_bias is not None:
+                                        v += self.row_bias[m[l] // self.rows_per_sample, col]
+                                    if self.residual is not None:
+                                        v += self.residual[m[l], col]
+                                    out_lin[m[l], col] = v
 
 
 def gelu_as(x):
@@ -345,7 +363,7 @@ def gelu_as(x):
     return x - h if x > 0 else h
 
 
-def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None):
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False):
     """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K]); conv = (B, H, W): 3x3 convolution of an
     NHWC image with Cin = K / 9 as an implicit GEMM (M = B H W)."""
     rng = np.random.default_rng(seed)
@@ -355,6 +373,9 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None)
     bias = rng.integers(-8, 9, size=wrows).astype(np.float64) / 4
     lin = np.full((M, wrows), np.nan)
     out = np.full((M, I), np.nan)
+    rps = conv[1] * conv[2] if conv else M          # rows per sample: H W for a convolution, one sample otherwise
+    row_bias = rng.integers(-8, 9, size=(M // rps, wrows)).astype(np.float64) / 4 if addends else None
+    residual = rng.integers(-8, 9, size=(M, wrows)).astype(np.float64) / 4 if addends else None
     nbn = I // BN if epi == 0 else -(-I // (2 * BN))
     nb = -(-M // BM) * nbn
     seen = set()
@@ -368,7 +389,8 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None)
         rb, cb = first + (tid % per_group) % rows_here, (tid % per_group) // rows_here
         assert 0 <= rb < nbm and 0 <= cb < nbn
         seen.add((rb, cb))
-        blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi, conv[1:] if conv else None)
+        blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi, conv[1:] if conv else None,
+                    row_bias, residual, rps)
         blk.flip = flip
         blk.run()
         blk.epilogue(lin, out)
@@ -382,6 +404,8 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None)
         ref = cols.reshape(M, K) @ w.T + bias
     else:
         ref = x @ w.T + bias
+    if addends:
+        ref = ref + np.repeat(row_bias, rps, axis=0) + residual
     ok_lin = np.array_equal(lin, ref)
     if epi == 1:
         return ok_lin, 0.0
@@ -394,7 +418,7 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm"], default=None)
+    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early"], default=None)
     ap.add_argument("--quick", action="store_true")
     a = ap.parse_args()
     # gelu polynomial against erf, float64
@@ -423,8 +447,10 @@ def main():
         for (Bn, H, Wd, Cin, N) in ([(2, 12, 12, 64, 128)] if a.quick else [(2, 12, 12, 64, 128), (1, 9, 20, 128, 200), (3, 8, 8, 64, 256)]):
             for mode in ("dma_early_read_late", "dma_late_read_early"):
                 ok, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd))
-                print(f"conv3x3 B={Bn} {H}x{Wd} Cin={Cin} N={N} {mode:>20s}: {'exact' if ok else 'WRONG'}")
-                bad += not ok
+                ok2, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd), addends=True, seed=1)
+                print(f"conv3x3 B={Bn} {H}x{Wd} Cin={Cin} N={N} {mode:>20s}: {'exact' if ok else 'WRONG'}; with per-sample bias + "
+                      f"residual (batch seams inside a tile): {'exact' if ok2 else 'WRONG'}")
+                bad += (not ok) + (not ok2)
     if a.breakage:
         print("replay", "caught the deliberately broken schedule" if bad else "DID NOT catch the broken schedule")
         sys.exit(0 if bad else 1)
