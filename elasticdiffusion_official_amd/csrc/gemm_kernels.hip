@@ -325,21 +325,14 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
 
   // bias: lane holds columns ncol + 4 f + j (f = fragment, j = accumulator register): 8 consecutive values, one 16-byte load each
   const int ncol = n0 + 32 * wcol + 8 * (lane >> 4);
-  float bv[2][4], bg[2][4];
-  {
-    u32x4 rv = {0, 0, 0, 0}, rg = {0, 0, 0, 0};
-    if (bias) {
-      if (EPI == 0 || ncol < I) rv = *reinterpret_cast<const u32x4*>(bias + ncol);
-      if (EPI == 0 || ncol + gap < I) rg = *reinterpret_cast<const u32x4*>(bias + gap + ncol);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bv[e >> 2][e & 3] = T::to_f32((uint16_t)(rv[e >> 1] >> (16 * (e & 1))));
-      bg[e >> 2][e & 3] = T::to_f32((uint16_t)(rg[e >> 1] >> (16 * (e & 1))));
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e)   // consumed here: no ordinary load is pending once the DMAs start
-      asm volatile("" : "+v"(bv[e >> 2][e & 3]), "+v"(bg[e >> 2][e & 3]));
+  // The two loads are issued BEFORE the first LDS-DMA and their values are first touched in the epilogue: they are the oldest
+  // entries of the VM queue, so every counted vmcnt of the schedule retires them on the way (in-order return), and the wave does
+  // not spend an L2 / HBM round trip waiting for 32 bytes before it may start staging (round 4; until then the values were
+  // converted -- i.e. waited for -- right here).
+  u32x4 bias_v = {0, 0, 0, 0}, bias_g = {0, 0, 0, 0};
+  if (bias) {
+    if (EPI == 0 || ncol < I) bias_v = *reinterpret_cast<const u32x4*>(bias + ncol);
+    if (EPI == 0 || ncol + gap < I) bias_g = *reinterpret_cast<const u32x4*>(bias + gap + ncol);
   }
 
   f32x4 acc[8][4];
@@ -393,6 +386,12 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   if (wrow == 0) ED_BARRIER();    // pair the extra barrier of the second wave row
 
   // epilogue: one 16-byte store per (lane, 16-row block): 8 consecutive columns of one row
+  float bv[2][4], bg[2][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e >> 2][e & 3] = T::to_f32((uint16_t)(bias_v[e >> 1] >> (16 * (e & 1))));
+    bg[e >> 2][e & 3] = T::to_f32((uint16_t)(bias_g[e >> 1] >> (16 * (e & 1))));
+  }
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {
     const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
