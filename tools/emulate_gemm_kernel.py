@@ -75,6 +75,7 @@ class Wave:
         self.xrd = rd + self.wrow * 8 * (2 * SUB)
         self.wrd = rd + W_REGION + self.wcol * 2 * (2 * SUB)
         self.acc = np.zeros((8, 4, 64, 4), np.float64)
+        self.done = []        # persistent variant: (m0, n0, accumulators) of the tiles this wave has finished
         self.frag = {}        # name -> [64, 8] values
         self.vmq = []         # outstanding DMAs, oldest first: (lds_byte_base, values[64, 8])
         self.pending = []     # outstanding fragment reads, oldest first: (name, lds byte addresses[64])
@@ -263,6 +264,61 @@ class Block:
         segs.append(lambda: self.mma16(wv, 1, 0))
         return segs
 
+    def retarget(self, wv, m0, n0):
+        """tools/gemm_persist: the workgroup moves on to its next tile -- the addresses `setup()` recomputes, a fresh accumulator."""
+        self.m0, self.n0 = m0, n0
+        fresh = Wave(self, wv.wave)
+        wv.x_voff, wv.px_mask, wv.w_voff = fresh.x_voff, fresh.px_mask, fresh.w_voff
+        wv.acc = np.zeros((8, 4, 64, 4), np.float64)
+
+    def program_persist(self, wv, tiles):
+        """The persistent experiment (tools/gemm_persist/gemm_persist.hip): this workgroup's tiles back to back; the NEXT tile's
+        prologue DMAs are issued in the interval that follows the barrier pair ending the current tile (before its epilogue, which
+        touches no LDS), and waited for at the top of the next tile exactly like a fresh workgroup's."""
+        nt = self.K // BK
+        early_start = nt >= 3
+        segs = []
+
+        def issue(j):
+            m0, n0 = tiles[j]
+            if self.pass_ != "rest":       # (the early-DMA mode runs every interval twice: bookkeeping in its first pass only)
+                if j > 0:
+                    wv.done.append((self.m0_of[wv.wave], self.n0_of[wv.wave], wv.acc.copy()))
+                self.m0_of[wv.wave], self.n0_of[wv.wave] = m0, n0
+                self.retarget(wv, m0, n0)
+            self.stage_w(wv, 0, 0, 0)
+            self.stage_x(wv, 0, 0, 0)
+            self.stage_w(wv, 0, 0, 1)
+            self.stage_x(wv, 0, 0, 1)
+            if nt > 1:
+                self.stage_w(wv, 1, 1, 0)
+                self.stage_x(wv, 1, 1, 0)
+                self.stage_w(wv, 1, 1, 1)
+                self.wait_vm(wv, 10 if early_start else 6)
+            else:
+                self.wait_vm(wv, 0)
+
+        for j in range(len(tiles)):
+            segs.append(lambda j=j: issue(j))
+            if wv.wrow == 1:
+                segs.append(lambda: None)
+            t = 0
+            while t + 1 < nt:
+                segs += self.tile_segments(wv, 0, t, True, t + 2 < nt, first=(t == 0 and early_start))
+                segs += self.tile_segments(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
+                t += 2
+            if t < nt:
+                segs += self.tile_segments(wv, 0, t, False, False)
+            if wv.wrow == 0:
+                segs.append(lambda: None)
+        segs.append(lambda: wv.done.append((self.m0_of[wv.wave], self.n0_of[wv.wave], wv.acc.copy())) if self.pass_ != "rest" else None)
+        return segs
+
+    def run_persist(self, tiles):
+        self.m0_of, self.n0_of = {}, {}
+        progs = [self.program_persist(wv, tiles) for wv in self.waves]
+        self._run_programs(progs)
+
     def program(self, wv):
         nt = self.K // BK
         segs = []
@@ -295,7 +351,9 @@ class Block:
         return segs
 
     def run(self):
-        progs = [self.program(wv) for wv in self.waves]
+        self._run_programs([self.program(wv) for wv in self.waves])
+
+    def _run_programs(self, progs):
         n = len(progs[0])
         assert all(len(p) == n for p in progs), "wave rows execute different numbers of barriers"
         for seg in range(n):
@@ -348,6 +406,47 @@ class Block:
                                     if self.residual is not None:
                                         v += self.residual[m[l], col]
                                     out_lin[m[l], col] = v
+
+
+def run_persist_case(M, K, N, mode, G, flip=False, seed=0):
+    """Plain projection through the persistent variant with a grid of G workgroups (tile ids b, b + G, ...)."""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-4, 5, size=(M, K)).astype(np.float64)
+    w = rng.integers(-4, 5, size=(N, K)).astype(np.float64)
+    bias = rng.integers(-8, 9, size=N).astype(np.float64) / 4
+    lin = np.full((M, N), np.nan)
+    nbn = -(-N // (2 * BN))
+    nb = -(-M // BM) * nbn
+
+    def tile_of(bid):
+        q, r, xcd = nb >> 3, nb & 7, bid & 7
+        tid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (bid >> 3)
+        nbm = nb // nbn
+        per_group = 8 * nbn
+        first = (tid // per_group) * 8
+        rows_here = min(nbm - first, 8)
+        return (first + (tid % per_group) % rows_here) * BM, ((tid % per_group) // rows_here) * 2 * BN
+
+    seen = set()
+    for b in range(min(G, nb)):
+        tiles = [tile_of(bid) for bid in range(b, nb, G)]
+        seen.update(tiles)
+        blk = Block(x, w, bias, M, K, N, tiles[0][0], tiles[0][1], mode, None, 1, None)
+        blk.flip = flip
+        blk.run_persist(tiles)
+        for wv in blk.waves:
+            assert len(wv.done) == len(tiles)
+        for j, (m0, n0) in enumerate(tiles):
+            blk.m0, blk.n0 = m0, n0
+            saved = [wv.acc for wv in blk.waves]
+            for wv in blk.waves:
+                assert wv.done[j][:2] == (m0, n0)
+                wv.acc = wv.done[j][2]
+            blk.epilogue(lin, None)
+            for wv, a in zip(blk.waves, saved):
+                wv.acc = a
+    assert len(seen) == nb
+    return np.array_equal(lin, x @ w.T + bias)
 
 
 def gelu_as(x):
@@ -420,7 +519,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early"], default=None)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--persist", action="store_true", help="replay the persistent experiment (tools/gemm_persist) instead")
     a = ap.parse_args()
+    if a.persist:
+        bad = 0
+        for (M, K, N, G) in [(768, 192, 768, 4), (512, 256, 512, 3), (300, 64, 640, 2)]:
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
+                    ok = run_persist_case(M, K, N, mode, G, flip)
+                    print(f"persistent M={M} K={K} ({K // BK} K tiles) N={N} grid {G} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
+                    bad += not ok
+        sys.exit(1 if bad else 0)
     # gelu polynomial against erf, float64
     xs = np.linspace(-12, 12, 48001)
     ge = np.array([gelu_as(v) for v in xs], np.float64)
