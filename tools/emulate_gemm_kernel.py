@@ -44,6 +44,20 @@ def w_sub(rg, kh):
 LANES = np.arange(64)
 
 
+# tools/gemm_sched/gemm_sched.hip's descriptors: (slot of the 8 pieces, pos, two-phase loop)
+SCHEDS = {
+    "product": ((0, 0, 2, 2, 4, 4, 6, 6), None, False),
+    "late": ((1, 1, 3, 3, 5, 5, 6, 6), None, False),
+    "mid": ((1, 1, 3, 3, 5, 5, 6, 6), None, False),
+    "spread": ((0, 1, 2, 3, 4, 5, 6, 6), None, False),
+    "mfma_all": ((1, 1, 3, 3, 5, 5, 7, 7), None, False),
+    "r4": ((0, 0, 2, 4, 6, 6, 6, 6), None, False),
+    "two_read": ((0, 0, 2, 2, 2, 2, 2, 2), None, True),
+    "two_mfma": ((0, 0, 3, 3, 3, 3, 3, 3), None, True),
+    "bad_early_b": ((0, 0, 0, 0, 4, 4, 6, 6), None, False),     # BROKEN ON PURPOSE: value rows re-staged in the phase that reads them
+}
+
+
 class Wave:
     """One wave's registers, DMA queue and pending reads."""
 
@@ -264,6 +278,82 @@ class Block:
         segs.append(lambda: self.mma16(wv, 1, 0))
         return segs
 
+    def tile_segments_b1(self, wv, tile, s1, s2, nxt):
+        """tools/gemm_persist v2 (`tile_phases_b1`): a K tile in buffer 1; ``nxt`` = (m0, n0) of the workgroup's next output tile when
+        this is the LAST K tile and it prefetches -- each phase then stages one half of the next tile's K tile 0 into buffer 0 (W value
+        rows, x m-half 0, W gate rows, x m-half 1) and phase 4 waits for nothing."""
+        if nxt is None:
+            return self.tile_segments(wv, 1, tile, s1, s2)
+        assert not s1 and not s2
+        brk = self.breakage
+
+        def nxt_wave():
+            keep = self.m0, self.n0
+            self.m0, self.n0 = nxt
+            fresh = Wave(self, wv.wave)
+            self.m0, self.n0 = keep
+            return fresh
+
+        def stage(kind, half, bufi=0):
+            fresh, mine = nxt_wave(), (wv.x_voff, wv.w_voff)
+            wv.x_voff, wv.w_voff = fresh.x_voff, fresh.w_voff
+            (self.stage_x if kind == "x" else self.stage_w)(wv, bufi, 0, half)
+            wv.x_voff, wv.w_voff = mine
+
+        segs = []
+        # BROKEN ON PURPOSE ("pf"): the first prefetch goes to buffer 1, whose value rows this very phase reads
+        segs.append(lambda: (self.read_w(wv, 1, 0), self.read_x(wv, 1, 0), stage("w", 0, 1 if brk == "pf" else 0), self.wait_lgkm(wv, 8)))
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 0)))
+        segs.append(lambda: (self.read_w(wv, 1, 1), stage("x", 0)))
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 0, 1)))
+        segs.append(lambda: (self.read_x(wv, 1, 1), stage("w", 1)))
+        segs.append(lambda: (self.wait_lgkm(wv, 0), self.mma16(wv, 1, 1)))
+        segs.append(lambda: stage("x", 1))
+        segs.append(lambda: self.mma16(wv, 1, 0))
+        return segs
+
+    # ---- tools/gemm_sched: the same loop from a schedule descriptor (slot / pos of the 8 pieces, see gemm_sched.hip) -------------
+    def piece(self, wv, bufi, tile, i, s1, s2):
+        op, k = i >> 1, i & 1
+        if op == 0:
+            if s1:
+                rg = (wv.wave & 3) + 8 * (wv.wave >> 2) + 4
+                self.dma(wv, 0, (bufi ^ 1) * BUF + x_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.x_voff[1] + (tile + 1) * (BK * 2) + 64 * k, 0)
+        elif op == 2:
+            if s2:
+                rg = (wv.wave & 3) + 8 * (wv.wave >> 2)
+                self.dma(wv, 0, bufi * BUF + x_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.x_voff[0] + (tile + 2) * (BK * 2) + 64 * k, 0)
+        elif s2:
+            g = 0 if op == 1 else 1
+            rg = 8 * g + wv.wave
+            self.dma(wv, 1, bufi * BUF + w_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.w_voff[g] + (tile + 2) * (BK * 2) + 64 * k, 0)
+
+    def tile_segments_sched(self, wv, bufi, tile, s1, s2, sched, first=False):
+        slot, two = SCHEDS[sched][0], SCHEDS[sched][2]
+        upto = lambda last, first_id=0: sum(slot[i] <= last for i in range(first_id, 8))    # noqa: E731
+        issue = lambda sl: [self.piece(wv, bufi, tile, i, s1, s2) for i in range(8) if slot[i] == sl]   # noqa: E731
+        early = (lambda n: self.wait_vm(wv, n)) if first else (lambda n: None)
+        tile_wait = lambda last: self.wait_vm(wv, upto(last, 2) if s2 else 0)   # noqa: E731
+        if two:
+            assert slot[0] <= 2 and slot[1] <= 2 and not first
+            return [
+                lambda: (self.read_w(wv, bufi, 0), self.read_x(wv, bufi, 0), self.read_w(wv, bufi, 1), issue(0), self.wait_lgkm(wv, 0)),
+                lambda: (issue(1), self.mma16(wv, 0, 0), self.mma16(wv, 0, 1)),
+                lambda: (self.read_x(wv, bufi, 1), issue(2), tile_wait(2), self.wait_lgkm(wv, 0)),
+                lambda: (issue(3), self.mma16(wv, 1, 1), self.mma16(wv, 1, 0)),
+            ]
+        assert slot[0] <= 6 and slot[1] <= 6
+        return [
+            lambda: (self.read_w(wv, bufi, 0), self.read_x(wv, bufi, 0), issue(0), self.wait_lgkm(wv, 8), early(14 + upto(0) - 6)),
+            lambda: (self.wait_lgkm(wv, 0), issue(1), self.mma16(wv, 0, 0), early(14 + upto(1) - 6)),
+            lambda: (self.read_w(wv, bufi, 1), issue(2), early(14 + upto(2) - 8)),
+            lambda: (self.wait_lgkm(wv, 0), issue(3), self.mma16(wv, 0, 1), early(14 + upto(3) - 8)),
+            lambda: (self.read_x(wv, bufi, 1), issue(4)),
+            lambda: (self.wait_lgkm(wv, 0), issue(5), self.mma16(wv, 1, 1)),
+            lambda: (issue(6), tile_wait(6)),
+            lambda: (issue(7), self.mma16(wv, 1, 0)),
+        ]
+
     def retarget(self, wv, m0, n0):
         """tools/gemm_persist: the workgroup moves on to its next tile -- the addresses `setup()` recomputes, a fresh accumulator."""
         self.m0, self.n0 = m0, n0
@@ -271,12 +361,13 @@ class Block:
         wv.x_voff, wv.px_mask, wv.w_voff = fresh.x_voff, fresh.px_mask, fresh.w_voff
         wv.acc = np.zeros((8, 4, 64, 4), np.float64)
 
-    def program_persist(self, wv, tiles):
+    def program_persist(self, wv, tiles, v2=False):
         """The persistent experiment (tools/gemm_persist/gemm_persist.hip): this workgroup's tiles back to back; the NEXT tile's
         prologue DMAs are issued in the interval that follows the barrier pair ending the current tile (before its epilogue, which
         touches no LDS), and waited for at the top of the next tile exactly like a fresh workgroup's."""
         nt = self.K // BK
         early_start = nt >= 3
+        prefetch = v2 and nt >= 6 and nt % 2 == 0      # v2: the last K tile (buffer 1) stages the next tile's K tile 0 into buffer 0
         segs = []
 
         def issue(j):
@@ -286,10 +377,11 @@ class Block:
                     wv.done.append((self.m0_of[wv.wave], self.n0_of[wv.wave], wv.acc.copy()))
                 self.m0_of[wv.wave], self.n0_of[wv.wave] = m0, n0
                 self.retarget(wv, m0, n0)
-            self.stage_w(wv, 0, 0, 0)
-            self.stage_x(wv, 0, 0, 0)
-            self.stage_w(wv, 0, 0, 1)
-            self.stage_x(wv, 0, 0, 1)
+            if not (prefetch and j > 0):
+                self.stage_w(wv, 0, 0, 0)
+                self.stage_x(wv, 0, 0, 0)
+                self.stage_w(wv, 0, 0, 1)
+                self.stage_x(wv, 0, 0, 1)
             if nt > 1:
                 self.stage_w(wv, 1, 1, 0)
                 self.stage_x(wv, 1, 1, 0)
@@ -305,7 +397,8 @@ class Block:
             t = 0
             while t + 1 < nt:
                 segs += self.tile_segments(wv, 0, t, True, t + 2 < nt, first=(t == 0 and early_start))
-                segs += self.tile_segments(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
+                pfn = prefetch and t + 2 == nt and j + 1 < len(tiles)
+                segs += self.tile_segments_b1(wv, t + 1, t + 2 < nt, t + 3 < nt, tiles[j + 1] if pfn else None)
                 t += 2
             if t < nt:
                 segs += self.tile_segments(wv, 0, t, False, False)
@@ -314,9 +407,9 @@ class Block:
         segs.append(lambda: wv.done.append((self.m0_of[wv.wave], self.n0_of[wv.wave], wv.acc.copy())) if self.pass_ != "rest" else None)
         return segs
 
-    def run_persist(self, tiles):
+    def run_persist(self, tiles, v2=False):
         self.m0_of, self.n0_of = {}, {}
-        progs = [self.program_persist(wv, tiles) for wv in self.waves]
+        progs = [self.program_persist(wv, tiles, v2) for wv in self.waves]
         self._run_programs(progs)
 
     def program(self, wv):
@@ -335,17 +428,18 @@ class Block:
                 self.wait_vm(wv, 10 if early_start else 6)   # early start: only the 4 DMAs phase 1 reads
             else:
                 self.wait_vm(wv, 0)
-        early_start = nt >= 3 and self.breakage != "noearly"
+        early_start = nt >= 3 and self.breakage != "noearly" and not (self.sched and SCHEDS[self.sched][2])
         segs.append(prologue)
         if wv.wrow == 1:
             segs.append(lambda: None)          # the extra barrier of the second wave row
+        ts = (lambda *a, **k: self.tile_segments_sched(*a, sched=self.sched, **k)) if self.sched else self.tile_segments
         t = 0
         while t + 1 < nt:
-            segs += self.tile_segments(wv, 0, t, True, t + 2 < nt, first=(t == 0 and early_start))
-            segs += self.tile_segments(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
+            segs += ts(wv, 0, t, True, t + 2 < nt, first=(t == 0 and early_start))
+            segs += ts(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
             t += 2
         if t < nt:
-            segs += self.tile_segments(wv, 0, t, False, False)
+            segs += ts(wv, 0, t, False, False)
         if wv.wrow == 0:
             segs.append(lambda: None)          # pairs the extra barrier
         return segs
@@ -375,6 +469,7 @@ class Block:
 
     pass_ = "all"
     flip = False
+    sched = None
 
     # ---- epilogue ---------------------------------------------------------------------------------------------------
     def epilogue(self, out_lin, out):
@@ -408,7 +503,7 @@ class Block:
                                     out_lin[m[l], col] = v
 
 
-def run_persist_case(M, K, N, mode, G, flip=False, seed=0):
+def run_persist_case(M, K, N, mode, G, flip=False, seed=0, v2=False, breakage=None):
     """Plain projection through the persistent variant with a grid of G workgroups (tile ids b, b + G, ...)."""
     rng = np.random.default_rng(seed)
     x = rng.integers(-4, 5, size=(M, K)).astype(np.float64)
@@ -431,9 +526,9 @@ def run_persist_case(M, K, N, mode, G, flip=False, seed=0):
     for b in range(min(G, nb)):
         tiles = [tile_of(bid) for bid in range(b, nb, G)]
         seen.update(tiles)
-        blk = Block(x, w, bias, M, K, N, tiles[0][0], tiles[0][1], mode, None, 1, None)
+        blk = Block(x, w, bias, M, K, N, tiles[0][0], tiles[0][1], mode, breakage, 1, None)
         blk.flip = flip
-        blk.run_persist(tiles)
+        blk.run_persist(tiles, v2)
         for wv in blk.waves:
             assert len(wv.done) == len(tiles)
         for j, (m0, n0) in enumerate(tiles):
@@ -462,7 +557,7 @@ def gelu_as(x):
     return x - h if x > 0 else h
 
 
-def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False):
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False, sched=None):
     """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K]); conv = (B, H, W): 3x3 convolution of an
     NHWC image with Cin = K / 9 as an implicit GEMM (M = B H W)."""
     rng = np.random.default_rng(seed)
@@ -491,6 +586,7 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
         blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi, conv[1:] if conv else None,
                     row_bias, residual, rps)
         blk.flip = flip
+        blk.sched = sched
         blk.run()
         blk.epilogue(lin, out)
     assert len(seen) == nb, "workgroup remap is not a bijection"
@@ -517,18 +613,54 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early"], default=None)
+    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early", "pf"], default=None)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--persist", action="store_true", help="replay the persistent experiment (tools/gemm_persist) instead")
+    ap.add_argument("--persist2", action="store_true", help="... its v2: the next tile's K tile 0 staged during the last K tile")
+    ap.add_argument("--sched", default=None, help="replay a schedule descriptor of tools/gemm_sched (name, or 'all')")
     a = ap.parse_args()
-    if a.persist:
+    if a.sched:
         bad = 0
-        for (M, K, N, G) in [(768, 192, 768, 4), (512, 256, 512, 3), (300, 64, 640, 2)]:
+        for name in (list(SCHEDS) if a.sched == "all" else [a.sched]):
+            want_bad = name.startswith("bad_")
+            caught = 0
+            for (M, K, N) in [(300, 448, 200), (256, 384, 256), (256, 128, 256), (256, 64, 128)]:
+                for mode in ("dma_early_read_late", "dma_late_read_early"):
+                    for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
+                        try:
+                            ok, _ = run_case(M, K, N, mode, flip, epi=1, sched=name)
+                        except AssertionError as e:
+                            ok = False
+                        caught += not ok
+                        if not want_bad:
+                            print(f"sched {name:>10s} M={M} K={K} ({K // BK} K tiles) N={N} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
+                            bad += not ok
+            if want_bad:
+                print(f"sched {name}: replay", "caught the deliberately broken schedule" if caught else "DID NOT catch the broken schedule")
+                bad += not caught
+        sys.exit(1 if bad else 0)
+    if a.breakage == "pf":
+        a.persist2 = True
+    if a.persist or a.persist2:
+        bad = 0
+        shapes = [(768, 192, 768, 4), (512, 256, 512, 3), (300, 64, 640, 2)]
+        if a.persist2:      # 6 and 8 K tiles prefetch; 7 (odd) and 4 (short) keep v1's order
+            shapes = [(768, 384, 768, 4), (512, 512, 512, 3), (512, 448, 512, 3), (300, 256, 640, 2)] if not a.breakage else [(512, 384, 512, 3)]
+        for (M, K, N, G) in shapes:
             for mode in ("dma_early_read_late", "dma_late_read_early"):
                 for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
-                    ok = run_persist_case(M, K, N, mode, G, flip)
-                    print(f"persistent M={M} K={K} ({K // BK} K tiles) N={N} grid {G} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
+                    try:
+                        ok = run_persist_case(M, K, N, mode, G, flip, v2=a.persist2, breakage=a.breakage)
+                    except AssertionError as e:
+                        if not a.breakage:
+                            raise
+                        ok = False
+                    print(f"persistent{' v2' if a.persist2 else ''} M={M} K={K} ({K // BK} K tiles) N={N} grid {G} {mode:>20s}"
+                          f"{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
                     bad += not ok
+        if a.breakage:
+            print("replay", "caught the deliberately broken schedule" if bad else "DID NOT catch the broken schedule")
+            sys.exit(0 if bad else 1)
         sys.exit(1 if bad else 0)
     # gelu polynomial against erf, float64
     xs = np.linspace(-12, 12, 48001)
