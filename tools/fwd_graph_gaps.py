@@ -1,6 +1,6 @@
 """How much of a hipGraph-replayed UNet forward is idle time BETWEEN kernels?
 
-    python tools/fwd_graph_gaps.py run [batch] [family]            # builds the fp16 UNet with the product's switches, captures one
+    python tools/fwd_graph_gaps.py run [batch] [family] [fp16|bf16]  # builds the UNet with the product's switches, captures one
                                                                     # forward (text k / v outside the graph), replays it 4 times
                                                                     # between marker kernels; prints the wall time per replay
     rocprofv3 --kernel-trace -d DIR -o NAME --output-format csv -- python tools/fwd_graph_gaps.py run 20
@@ -18,13 +18,13 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(batch, fam):
+def run(batch, fam, dtype="fp16"):
     import torch
 
     import elasticdiffusion_official_amd  # noqa: F401
     from elasticdiffusion_official_amd import models as M
     cfg = M.UNET_CONFIGS[fam]
-    dt = torch.float16
+    dt = torch.float16 if dtype == "fp16" else torch.bfloat16
     torch.manual_seed(0)
     unet = M.UNet2DConditionModel(**cfg).to("cuda", dt).eval().requires_grad_(False)
     if M.CHANNELS_LAST:
@@ -60,7 +60,7 @@ def run(batch, fam):
         walls.append(round(1e3 * (time.perf_counter() - t0), 2))
     marker.cumsum(0)
     torch.cuda.synchronize()
-    print(json.dumps({"family": fam, "batch": batch, "replay_wall_ms_host_clock": walls, "finite": bool(torch.isfinite(out).all())}), flush=True)
+    print(json.dumps({"family": fam, "batch": batch, "dtype": dtype, "replay_wall_ms_host_clock": walls, "finite": bool(torch.isfinite(out).all())}), flush=True)
 
 
 def short(name):
@@ -106,11 +106,18 @@ def analyse(path):
                      "gap_hist": dict(hist), "gap_after_kernel": top(after), "gap_before_kernel": top(before),
                      "short_kernels_lt10us": sum(1 for s, e, _ in seg if e - s < 10000),
                      "short_kernels_busy_ms": round(sum(e - s for s, e, _ in seg if e - s < 10000) / 1e6, 3)})
-    print(json.dumps({"replays": reps}))
+    # per-kernel totals of the LAST replay (full names cut to 110 characters: enough to tell the library's instances apart)
+    fam = collections.defaultdict(lambda: [0, 0])
+    if marks and len(marks) >= 2:
+        for s_, e_, n_ in ev[marks[-2] + 1:marks[-1]]:
+            fam[n_[:110]][0] += 1
+            fam[n_[:110]][1] += e_ - s_
+    kernels = [{"name": k, "calls": v[0], "total_ms": round(v[1] / 1e6, 3)} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])]
+    print(json.dumps({"replays": reps, "kernels_last_replay": kernels}))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(int(sys.argv[2]) if len(sys.argv) > 2 else 20, sys.argv[3] if len(sys.argv) > 3 else "sdxl")
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 20, sys.argv[3] if len(sys.argv) > 3 else "sdxl", sys.argv[4] if len(sys.argv) > 4 else "fp16")
     else:
         analyse(sys.argv[2])
