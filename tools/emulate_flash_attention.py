@@ -233,6 +233,119 @@ def run_block_gen(q, k, v, Nq, Nk, qblk, scale, DH, poison=np.nan):
     return out
 
 
+# ---- tools/attn16: the same transposed-contraction design on v_mfma_f32_16x16x32 (round-5 experiment) --------------------------
+#   v_mfma_f32_16x16x32:  A[i = lane&15][k = 8*(lane>>4) + j]   B[k = 8*(lane>>4) + j][n = lane&15]   j = 0..7
+#                         D[row = 4*(lane>>4) + r][col = lane&15]                                      r = 0..3
+# (the layout csrc/gemm_kernels.hip runs on; tools/emulate_gemm_kernel.py).  A wave still owns 32 query rows, now as two 16-column
+# blocks qb: a lane holds queries (lane&15) and 16 + (lane&15), and 16 of a tile's 64 keys for each (key blocks kb = 0..3, rows
+# 4 g + r, g = lane>>4).  P as the B operand of key step st (32 keys): slots j = 0..3 <-> key 16 (2 st) + 4 g + j, slots 4..7 <->
+# key 16 (2 st + 1) + 4 g + (j - 4) -- the accumulator registers of key blocks 2 st and 2 st + 1, no shuffle.
+V_LD_16 = 80      # V tile row pitch (elements): 160 B -- 8 consecutive rows x 4 8-byte chunks of a transpose read hit 64 distinct banks
+
+
+def mfma_16x16x32(A, B, C):
+    """A, B: [64 lanes, 8]; C: [64 lanes, 4]."""
+    Am, Bm = np.zeros((16, 32)), np.zeros((32, 16))
+    for lane in range(64):
+        for j in range(8):
+            Am[lane & 15, 8 * (lane >> 4) + j] = A[lane, j]
+            Bm[8 * (lane >> 4) + j, lane & 15] = B[lane, j]
+    Dm = Am @ Bm
+    out = C.copy()
+    for lane in range(64):
+        for r in range(4):
+            out[lane, r] += Dm[4 * (lane >> 4) + r, lane & 15]
+    return out
+
+
+def swz_g(pos):
+    """csrc/gemm_kernels.hip's st_16x32 image: byte position inside a [16 rows][64 bytes] subtile, rows 8..15 with their halves swapped"""
+    return pos ^ (((pos >> 9) & 1) << 5)
+
+
+def run_block_p16(q, k, v, Nq, Nk, qblk, scale, poison=np.nan):
+    """One workgroup (4 waves x 32 query rows) of k_flash_attn_p16: Nk a multiple of 64.  LDS is poisoned: a fragment read that
+    touches a byte the staging did not write shows as NaN."""
+    assert Nk % KT == 0
+    out = {}
+    lanes = np.arange(64)
+    m16, g = lanes & 15, lanes >> 4
+    sl = scale * np.log2(np.e)
+    for wave in range(4):
+        q_row = [qblk * QB + wave * 32 + 16 * qb + m16 for qb in range(2)]
+        qf = np.zeros((2, 2, 64, 8))
+        for qb in range(2):
+            for ks in range(2):
+                for l in range(64):
+                    if q_row[qb][l] < Nq:
+                        qf[qb, ks, l] = q[q_row[qb][l], 32 * ks + 8 * g[l]: 32 * ks + 8 * g[l] + 8]
+        oacc = np.zeros((4, 2, 64, 4))
+        m_run = np.full((2, 64), -np.inf)
+        l_run = np.zeros((2, 64))
+        for t in range(Nk // KT):
+            k_lds = np.full(KT * D, poison)               # elements; 8 subtiles of 512 elements (1024 B)
+            v_lds = np.full(KT * V_LD_16, poison)
+            for tid in range(256):
+                st_row, chunk = tid >> 3, tid & 7
+                for i in range(2):
+                    row = st_row + 32 * i
+                    kb, r, ks, c = row >> 4, row & 15, chunk >> 2, (chunk & 3) * 16
+                    dst = ((kb * 2 + ks) * 1024 + swz_g(r * 64 + c)) // 2
+                    k_lds[dst:dst + 8] = k[t * KT + row, 8 * chunk: 8 * chunk + 8]
+                    v_lds[row * V_LD_16 + 8 * chunk: row * V_LD_16 + 8 * chunk + 8] = v[t * KT + row, 8 * chunk: 8 * chunk + 8]
+            s = np.zeros((4, 2, 64, 4))
+            for ks in range(2):
+                for kb in range(4):
+                    kf = np.zeros((64, 8))
+                    for l in range(64):
+                        a0 = ((kb * 2 + ks) * 1024 + swz_g(m16[l] * 64 + 16 * g[l])) // 2
+                        kf[l] = k_lds[a0:a0 + 8]
+                    for qb in range(2):
+                        s[kb, qb] = mfma_16x16x32(kf, qf[qb, ks], s[kb, qb])
+            for qb in range(2):
+                mx = s[:, qb].max((0, 2))
+                mx = np.maximum(mx, mx[lanes ^ 16])
+                mx = np.maximum(mx, mx[lanes ^ 32])
+                m_new = np.maximum(m_run[qb], mx)
+                alpha = np.exp2(m_run[qb] * sl - m_new * sl)
+                m_run[qb] = m_new
+                e = np.exp2(s[:, qb] * sl - (m_new * sl)[None, :, None])
+                l_run[qb] = l_run[qb] * alpha + e.sum((0, 2))
+                oacc[:, qb] *= alpha[None, :, None]
+                for st in range(2):
+                    pf = np.concatenate([e[2 * st], e[2 * st + 1]], 1)            # slots 0..3: key block 2 st, 4..7: 2 st + 1
+                    for db in range(4):
+                        row = 4 * g + (m16 >> 2)
+                        col = 16 * db + 4 * (lanes & 3)
+                        lo = tr_read(v_lds, (16 * (2 * st) + row) * V_LD_16 + col)
+                        hi4 = tr_read(v_lds, (16 * (2 * st + 1) + row) * V_LD_16 + col)
+                        oacc[db, qb] = mfma_16x16x32(np.concatenate([lo, hi4], 1), pf, oacc[db, qb])
+        for qb in range(2):
+            l_tot = l_run[qb] + l_run[qb][lanes ^ 16]
+            l_tot = l_tot + l_tot[lanes ^ 32]
+            for l in range(64):
+                if q_row[qb][l] < Nq:
+                    o = out.setdefault(int(q_row[qb][l]), np.zeros(D))
+                    for db in range(4):
+                        for r in range(4):
+                            o[16 * db + 4 * g[l] + r] = oacc[db, qb][l, r] / l_tot[l]
+    return out
+
+
+def v16_bank_check():
+    """ds_read_b64_tr_b16 services lanes 0..31 and 32..63 in one LDS cycle each: the 32 8-byte reads must cover 64 distinct banks."""
+    lanes = np.arange(64)
+    for kb in range(4):
+        for db in range(4):
+            addr = ((16 * kb + 4 * (lanes >> 4) + ((lanes & 15) >> 2)) * V_LD_16 + 16 * db + 4 * (lanes & 3)) * 2      # bytes
+            for half in (lanes[:32], lanes[32:]):
+                banks = set()
+                for a in addr[half]:
+                    banks.update((((a // 4) + i) % 64) for i in range(2))
+                assert len(banks) == 64, (kb, db, sorted(banks))
+    return True
+
+
 def reference(q, k, v, scale):
     s = (q @ k.T) * scale
     p = np.exp(s - s.max(1, keepdims=True))
@@ -261,4 +374,16 @@ if __name__ == "__main__":
             err = max(np.abs(got[r] - want[r]).max() for r in got)
             print(f"head_dim {DH} Nq={Nq} Nk={Nk}: rows={len(got)} max|err|={err:.2e}")
             assert len(got) == min(Nq, QB) and err < 1e-12
+    assert v16_bank_check()
+    for (Nq, Nk) in [(128, 128), (100, 192), (260, 64)]:
+        q, k, v = rng.standard_normal((Nq, D)), rng.standard_normal((Nk, D)), rng.standard_normal((Nk, D))
+        want = reference(q, k, v, 0.125)
+        err, rows = 0.0, 0
+        for qblk in range((Nq + QB - 1) // QB):
+            got = run_block_p16(q, k, v, Nq, Nk, qblk, 0.125)
+            for r, o in got.items():
+                err = max(err, np.abs(o - want[r]).max())
+                rows += 1
+        print(f"16x16x32 experiment Nq={Nq} Nk={Nk}: rows={rows} max|err|={err:.2e}")
+        assert rows == Nq and err < 1e-12
     print("index math OK")
