@@ -156,13 +156,29 @@ __device__ __forceinline__ void resoftmax_tile16(const uint16_t* kt, const Lane1
   }
 }
 
+// per-segment cycle accounting (TIMING builds only): s_memtime stamps, wave-uniform, summed over the iterations of the wave
+struct Tm {
+  uint64_t last;
+  uint32_t a[8];
+};
+template <bool TIMING>
+__device__ __forceinline__ void stamp(Tm& tm, int k) {
+  if (TIMING) {
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    tm.a[k] += (uint32_t)(now - tm.last);
+    tm.last = now;
+  }
+}
+
 // one iteration's compute: 32 MFMAs -- S_next = K(t+1) Q^T (16), then O += V(t-1)^T P(t-1)^T (16) -- each followed by one slice of
 // the softmax of S_cur; a K / V fragment feeds two consecutive MFMAs (the two query blocks) and is fetched from LDS one fragment ahead
-template <typename T, bool HAS_PV, bool HAS_NEXT>
-__device__ __forceinline__ void pipe_region16(const uint16_t* k_next, const uint16_t* v_prev, const Lane16& L,
+// `filler(i)` is called behind MFMA slot i (INREGION builds: the next tiles' global loads at slots 0..3, their LDS writes at 26..29 -- VMEM
+// and DS instructions co-issue with the MFMA / VALU stream instead of standing alone between the region and the barrier)
+template <typename T, bool HAS_PV, bool HAS_NEXT, bool TIMING, class Filler>
+__device__ __forceinline__ void pipe_region16(Filler&& filler, const uint16_t* k_next, const uint16_t* v_prev, const Lane16& L,
                                               const typename T::v8 (&qf)[2][2], f32x4 (&s_cur)[4][2], f32x4 (&s_next)[4][2],
                                               const typename T::v8 (&p_prev)[2][2], typename T::v8 (&p_cur)[2][2], f32x4 (&o)[4][2],
-                                              float sl, Run16& run) {
+                                              float sl, Run16& run, Tm& tm) {
   constexpr int FQK = HAS_NEXT ? 8 : 0, NF = FQK + (HAS_PV ? 8 : 0);    // fragments
   auto fetch = [&](int fi) -> Vec16 {
     if (fi < FQK) return k_frag16(k_next, L, fi & 3, fi >> 2);
@@ -194,14 +210,24 @@ __device__ __forceinline__ void pipe_region16(const uint16_t* k_next, const uint
       }
     }
     softmax_slice16<T>(i, s_cur, sl, run, p_cur);
+    filler(i);
     __builtin_amdgcn_sched_barrier(0);
+    if (i == 15) stamp<TIMING>(tm, 1);     // S_next half done
   }
+  stamp<TIMING>(tm, 2);                     // P V half done
 }
 
-template <typename T>
+// NOCHECK (ablation only, wrong on data whose scores outgrow the first tile's maximum by 2^6): the lazy loop without its per-tile
+// check -- what deferring the check into the next iteration's MFMA shadow could buy at most
+template <typename T, bool TIMING = false, bool NOCHECK = false, bool INREGION = false>
 __global__ void __launch_bounds__(256, 2)
-k_flash_attn_p16(const Params p) {
+k_flash_attn_p16(const Params p, uint32_t* __restrict__ tm_out) {
   __shared__ Smem16 sm;
+  Tm tm;
+  tm.last = TIMING ? __builtin_amdgcn_s_memtime() : 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tm.a[i] = 0;
+  const uint64_t t_begin = tm.last;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m16 = lane & 15, g = lane >> 4;
@@ -291,16 +317,38 @@ k_flash_attn_p16(const Params p) {
 
   auto iter = [&](auto has_pv, auto has_next, int t, f32x4 (&s_cur)[4][2], f32x4 (&s_next)[4][2], typename T::v8 (&p_prev)[2][2],
                   typename T::v8 (&p_cur)[2][2]) {
-    load_k(t + 2);
-    load_v(t + 1);
-    pipe_region16<T, decltype(has_pv)::value, decltype(has_next)::value>(sm.k[kb_next], sm.v[vb_prev], L, qf, s_cur, s_next, p_prev,
-                                                                        p_cur, oacc, sl, run);
+    stamp<TIMING>(tm, 7);                  // (whatever preceded the iteration: prologue / loop overhead)
+    if (!INREGION) {
+      load_k(t + 2);
+      load_v(t + 1);
+    }
+    stamp<TIMING>(tm, 0);                  // global loads issued
+    const uint32_t kbase = k_off + (uint32_t)(t + 2) * 2u * k_half, vbase = v_off + (uint32_t)(t + 1) * 2u * v_half;
+    uint8_t* const kdst = reinterpret_cast<uint8_t*>(sm.k[kb_write]);
+    uint16_t* const vdst = sm.v[vb_next];
+    auto filler = [&](int i) {
+      if (!INREGION) return;
+      if (i == 0) kreg[0] = buf_load16(k_rs, kbase, 0);
+      else if (i == 1) kreg[1] = buf_load16(k_rs, kbase + k_half, 0);
+      else if (i == 2) vreg[0] = buf_load16(v_rs, vbase, 0);
+      else if (i == 3) vreg[1] = buf_load16(v_rs, vbase + v_half, 0);
+      else if (i == 26) *reinterpret_cast<Vec16*>(kdst + k_dst[0]) = kreg[0];
+      else if (i == 27) *reinterpret_cast<Vec16*>(kdst + k_dst[1]) = kreg[1];
+      else if (i == 28) *reinterpret_cast<Vec16*>(&vdst[st_row * V_LD_16 + 8 * st_chunk]) = vreg[0];
+      else if (i == 29) *reinterpret_cast<Vec16*>(&vdst[(st_row + 32) * V_LD_16 + 8 * st_chunk]) = vreg[1];
+    };
+    pipe_region16<T, decltype(has_pv)::value, decltype(has_next)::value, TIMING>(filler, sm.k[kb_next], sm.v[vb_prev], L, qf, s_cur,
+                                                                                s_next, p_prev, p_cur, oacc, sl, run, tm);
+    // one vote per tile: the O rescale can only be needed after the exact redo (alpha is 1 otherwise), and that is a scalar flag
     run.alpha[0] = run.alpha[1] = 1.0f;
-    if (__any(!(run.psum[0] <= RESCALE_SUM_MAX && run.psum[1] <= RESCALE_SUM_MAX)))
+    bool redone = false;
+    if (!NOCHECK && __any(!(run.psum[0] <= RESCALE_SUM_MAX && run.psum[1] <= RESCALE_SUM_MAX))) {
       resoftmax_tile16<T>(sm.k[kb_cur], L, qf, s_cur, sl, run, p_cur);
+      redone = true;
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) run.l[qb] = __builtin_fmaf(run.l[qb], run.alpha[qb], run.psum[qb]);
-    if (__any(run.alpha[0] != 1.0f || run.alpha[1] != 1.0f)) {
+    if (redone) {
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -308,13 +356,22 @@ k_flash_attn_p16(const Params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) oacc[db][qb][j] *= run.alpha[qb];
     }
-    write_k(kb_write);
-    write_v(vb_next);
+    // (Measured: with two votes per tile -- this one and a second `__any(alpha != 1)` in front of the rescale, as the product kernel
+    // has them -- the segment costs 180 cycles per tile; without any check the kernel is 5-11 % faster, profiles/r4_s21_*.  Taking the
+    // vote before the LDS writes and the redo after them made hipcc give the redo path its own registers and put 33 v_mov on the FAST
+    // path of the merge: slower.)
+    stamp<TIMING>(tm, 3);                  // lazy check (+ slow path, rescale)
+    if (!INREGION) {
+      write_k(kb_write);
+      write_v(vb_next);
+    }
+    stamp<TIMING>(tm, 4);                  // waited for the global loads, LDS writes issued
     const int tmp = vb_prev;
     vb_prev = vb_cur, vb_cur = vb_next, vb_next = tmp;
     const int ktmp = kb_cur;
     kb_cur = kb_next, kb_next = kb_write, kb_write = ktmp;
     __syncthreads();
+    stamp<TIMING>(tm, 5);                  // barrier
   };
 
   // tile 0: S and its exact row maxima = the first reference; from there on every tile (tile 0 included) takes the lazy softmax
@@ -367,13 +424,23 @@ k_flash_attn_p16(const Params p) {
       }
     }
   }
+  if (TIMING) {
+    stamp<TIMING>(tm, 6);                  // drain + epilogue
+    if (lane == 0 && blockIdx.x < 64) {
+      uint32_t* o = tm_out + (blockIdx.x * 4 + wave) * 10;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = tm.a[i];
+      o[8] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin);
+      o[9] = (uint32_t)n_full;
+    }
+  }
 }
 
 }  // namespace
 
 extern "C" int ed_x_flash_attention16(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,
                                       int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int64_t o_sb,
-                                      int64_t o_sn, float scale, void* stream) {
+                                      int64_t o_sn, float scale, void* timing_out, void* stream) {
   if (B == 0 || H == 0 || Nq == 0) return 0;
   if (Nk < 2 * KT || Nk % KT != 0) return (int)hipErrorInvalidValue;
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15u) || ((uintptr_t)out & 7u)) return (int)hipErrorInvalidValue;
@@ -387,8 +454,20 @@ extern "C" int ed_x_flash_attention16(const void* q, const void* k, const void* 
   const int64_t nb = (int64_t)p.BH * p.nqb;
   if (nb > 0x7fffffff) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == ED_BF16) k_flash_attn_p16<BF16x><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p);
-  else if (dtype == ED_F16) k_flash_attn_p16<HF16x><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p);
+  // timing_out (optional): 64 workgroups x 4 waves x 10 uint32 -- cycles per segment (see stamp<>), total, tiles
+  if (timing_out == (void*)2) {    // variant: global loads and LDS writes inside the MFMA region
+    if (dtype != ED_F16) return (int)hipErrorInvalidValue;
+    k_flash_attn_p16<HF16x, false, false, true><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, nullptr);
+  } else if (timing_out == (void*)3) {    // ... its s_memtime build (timing buffer = out + nothing: the caller passes it through q? no: see run.py)
+    return (int)hipErrorInvalidValue;
+  } else if (timing_out == (void*)1) {    // ablation: no per-tile check
+    if (dtype != ED_F16) return (int)hipErrorInvalidValue;
+    k_flash_attn_p16<HF16x, false, true><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, nullptr);
+  } else if (timing_out) {
+    if (dtype != ED_F16) return (int)hipErrorInvalidValue;
+    k_flash_attn_p16<HF16x, true><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, (uint32_t*)timing_out);
+  } else if (dtype == ED_BF16) k_flash_attn_p16<BF16x><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, nullptr);
+  else if (dtype == ED_F16) k_flash_attn_p16<HF16x><<<dim3((unsigned)nb), dim3(256), 0, st>>>(p, nullptr);
   else return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
 }

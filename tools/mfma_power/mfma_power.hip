@@ -75,3 +75,74 @@ extern "C" int ed_mfma_loop(int shape, int bf, int nacc, const void* in, void* o
 #undef GO
   return (int)hipErrorInvalidValue;
 }
+
+// ---- VALU issue rates next to it: what does one softmax numerator cost?  8 independent chains per lane, OP per chain element:
+//   0  v_fma_f32         1  v_exp_f32         2  v_fma_f32 + v_exp_f32 + v_add_f32 (one lazy-softmax numerator)
+//   3  as 2, and one 16x16x32 MFMA per 2 numerators (4 per iteration)
+//   4  as 2, and one 32x32x16 MFMA per 4 numerators (2 per iteration: the same MACs as 3), 8 accumulators in rotation
+//   5  4 MFMAs 16x16x32 alone          6  2 MFMAs 32x32x16 alone (8 accumulators in rotation)
+template <int OP>
+__global__ void __launch_bounds__(512, 2) k_valu_loop(const float* __restrict__ in, float* __restrict__ out, int iters) {
+  const int t = blockIdx.x * 512 + threadIdx.x;
+  float x[8], acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = in[(size_t)t * 8 + i];
+  const float a = in[0] * 1e-9f + 0.999f, b = in[1] * 1e-9f - 0.01f;
+  f32x4 macc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) macc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f16x8 ma = __builtin_bit_cast(f16x8, u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
+  f32x16 bacc[8];
+  if (OP == 4 || OP == 6) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bacc[j][e] = 0.f;
+  }
+  for (int it4 = 0; it4 < iters; it4 += 4) {
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (OP == 5) {
+        if (i & 1) macc[i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ma, ma, macc[i >> 1], 0, 0, 0);
+      } else if (OP == 6) {
+        if ((i & 3) == 3) bacc[2 * u + (i >> 2)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ma, ma, bacc[2 * u + (i >> 2)], 0, 0, 0);
+      } else if (OP == 0) {
+        x[i] = __builtin_fmaf(x[i], a, b);
+      } else if (OP == 1) {
+        x[i] = __builtin_amdgcn_exp2f(x[i]) - 1.0f;     // (keeps the chain bounded: one extra v_add per exp, reported as such)
+      } else {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], a, b));
+        acc += e;
+        x[i] = e - 1.0f;
+        if (OP == 3 && (i & 1)) macc[i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ma, ma, macc[i >> 1], 0, 0, 0);
+        if (OP == 4 && (i & 3) == 3) bacc[2 * u + (i >> 2)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ma, ma, bacc[2 * u + (i >> 2)], 0, 0, 0);
+      }
+    }
+   }
+  }
+  if (OP == 4 || OP == 6) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += bacc[j][0];
+  }
+  float s = acc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += x[i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += macc[j][0];
+  out[t] = s;
+}
+
+extern "C" int ed_valu_loop(int op, const void* in, void* out, int blocks, int iters, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (op == 0) k_valu_loop<0><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else if (op == 1) k_valu_loop<1><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else if (op == 2) k_valu_loop<2><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else if (op == 3) k_valu_loop<3><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else if (op == 4) k_valu_loop<4><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else if (op == 5) k_valu_loop<5><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else if (op == 6) k_valu_loop<6><<<blocks, 512, 0, s>>>((const float*)in, (float*)out, iters);
+  else return (int)hipErrorInvalidValue;
+  return (int)hipGetLastError();
+}
