@@ -30,6 +30,23 @@ def attn16(q, k, v, H, timing=None):
     return out
 
 
+X5 = None
+
+
+def attn5_inregion(q, k, v, H):
+    global X5
+    if X5 is None:
+        X5 = ctypes.CDLL(os.path.join(HERE, "libattn5_inregion.so"))
+        X5.ed_x_flash_attention5_inregion.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_i64] * 8 + [_f, _vp]
+    B, Nq, HD = q.shape
+    out = torch.empty(B, Nq, HD, dtype=q.dtype, device=q.device)
+    rc = X5.ed_x_flash_attention5_inregion(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), 1 if q.dtype == torch.float16 else 2, B, H, Nq,
+                                           k.shape[1], q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0),
+                                           out.stride(1), 64 ** -0.5, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    return out
+
+
 def ref(q, k, v, H):
     B, N, HD = q.shape
     f = lambda t: t.float().reshape(B, t.shape[1], H, 64).transpose(1, 2)   # noqa: E731
@@ -53,6 +70,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--segments", action="store_true", help="only the s_memtime build: where a wave's cycles go")
 ap.add_argument("--inregion", action="store_true", help="only the variant with the global loads / LDS writes inside the MFMA region")
+ap.add_argument("--product-inregion", action="store_true", help="only the PRODUCT kernel's in-region variant (attn5_inregion.hip) vs v_path 5")
 ap.add_argument("--nocheck", action="store_true", help="only the ablation without the lazy loop's per-tile check")
 a = ap.parse_args()
 assert (ops.ED_F16, ops.ED_BF16) == (1, 2)
@@ -77,6 +95,32 @@ if a.segments:
                "share_of_wave_total": {SEG[i]: round(float(t[:, i].mean() / t[:, 8].mean()), 3) for i in range(8)},
                "spread_over_waves_cycles_per_tile_min_max": {SEG[i]: [round(float(t[:, i].min()) / tiles, 1), round(float(t[:, i].max()) / tiles, 1)] for i in (1, 2, 4, 5)}}
         print(json.dumps(rec), flush=True)
+    sys.exit(0)
+if a.product_inregion:
+    for dt in (torch.float16, torch.bfloat16):
+        for (B, H, Nq, Nk, outlier) in [(2, 3, 256, 256, False), (1, 2, 200, 200, False), (2, 2, 384, 1024, False), (1, 2, 256, 512, True), (1, 3, 130, 333, False)]:
+            qkv = torch.randn(B, max(Nq, Nk), 3 * H * 64, device="cuda", generator=g).to(dt)
+            q, k, v = qkv[:, :Nq, :H * 64], qkv[:, :Nk, H * 64:2 * H * 64], qkv[:, :Nk, 2 * H * 64:]
+            if outlier:
+                k = k.clone()
+                k[:, 300:303] = (q[:, 5:8] * 6).to(dt)
+                k[:, 450] = (q[:, 100] * 12).to(dt)
+            same = all(bool(torch.equal(ops.flash_attention(q, k, v, H, v_path=5), attn5_inregion(q, k, v, H))) for _ in range(4))
+            print(json.dumps({"check": "product kernel, in-region variant == v_path 5, bit for bit (4 runs)", "dtype": str(dt)[6:], "B": B, "H": H, "Nq": Nq,
+                              "Nk": Nk, "outlier_keys": outlier, "ok": same}), flush=True)
+    for dt in (torch.float16, torch.bfloat16):
+        for (B, H, N) in [(20, 10, 4096), (20, 20, 1024), (6, 10, 4096), (6, 20, 1024)]:
+            qkv = torch.randn(B, N, 3 * H * 64, device="cuda", generator=g).to(dt)
+            q, k, v = qkv[..., :H * 64], qkv[..., H * 64:2 * H * 64], qkv[..., 2 * H * 64:]
+            t5, tn = [], []
+            for _ in range(a.rounds):
+                t5.append(timed(lambda: ops.flash_attention(q, k, v, H, v_path=5)))
+                tn.append(timed(lambda: attn5_inregion(q, k, v, H)))
+            med = lambda x: sorted(x)[len(x) // 2]   # noqa: E731
+            flops = 4.0 * B * H * N * N * 64
+            print(json.dumps({"check": "timing: product kernel with loads / LDS writes inside the region", "dtype": str(dt)[6:], "B": B, "H": H, "N": N,
+                              "product_v5_tflops": round(flops / med(t5) / 1e9, 1), "inregion_tflops": round(flops / med(tn) / 1e9, 1),
+                              "speedup": round(med(t5) / med(tn), 4)}), flush=True)
     sys.exit(0)
 if a.inregion:
     for (B, H, Nq, Nk) in [(2, 3, 256, 256), (1, 2, 200, 128), (2, 2, 384, 1024)]:
