@@ -1,7 +1,8 @@
 // attn5_inregion.hip -- EXPERIMENT for round 5 (not in libelastic_hip.so): the PRODUCT's pipelined lazy attention kernel (v_path 5, 32x32x16
 // layout) with the next tiles' global loads issued behind MFMA slots 0..3 of the loop's MFMA region and their LDS writes behind slots 11..14,
 // instead of in front of / behind the region (tools/attn16 measured +3...5 % for this change on the 16x16x32 rebuild).  The kernel text below
-// is generated from csrc/attention_kernels.hip by tools/attn16/make_attn5_inregion.py (region + kernel copied, four edits); results must be
+// is generated from csrc/attention_kernels.hip by tools/attn16/make_attn5_inregion.py (region + kernel copied, five edits -- the fifth: the
+// prologue's K(0), V(0), K(1) loads in flight together); results must be
 // bit-identical to ed_flash_attention(v_path = 5).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I include tools/attn16/attn5_inregion.hip -o tools/attn16/libattn5_inregion.so
 #include "../../elasticdiffusion_official_amd/csrc/attention_kernels.hip"
@@ -129,12 +130,13 @@ k_flash_attn_pipe_ir(const Params p) {
 
   load_k(0);
   load_v(0);
+  Vec16 k1reg[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) k1reg[i] = buf_load16(k_rs, k_off + 2u * k_half + i * k_half, 0);   // K(1): rows past Nk read as zeros
   write_k(0);
   write_v(0);
-  if (n_tiles > 1) {
-    load_k(1);
-    write_k(1);
-  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) *reinterpret_cast<Vec16*>(&sm.k[1][(st_row + 32 * i) * K_LD + st_col]) = k1reg[i];
   __syncthreads();
 
   // ping-pong register sets (named, statically indexed: no copies between iterations)

@@ -45,6 +45,28 @@ kern = sub(kern, """    load_k(t + 2);  // unconditional: a tile past the end re
 kern = sub(kern, "pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2, DEPTH>(sm.k[kb_next],",
            "pipe_region_ir<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2, DEPTH>(filler, sm.k[kb_next],")
 kern = sub(kern, "    write_k(kb_write);\n    write_v(vb_next);\n    const int tmp = vb_prev;", "    const int tmp = vb_prev;")
+# edit 5: the prologue's three tile loads (K(0), V(0), K(1)) in flight together instead of K(1) after the first two have been waited for and
+# written: one memory round trip less before the first MFMA (tools/attn16's stamps: the prologue is 9-15 % of a wave's cycles)
+kern = sub(kern, """  load_k(0);
+  load_v(0);
+  write_k(0);
+  write_v(0);
+  if (n_tiles > 1) {
+    load_k(1);
+    write_k(1);
+  }
+  __syncthreads();
+""", """  load_k(0);
+  load_v(0);
+  Vec16 k1reg[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) k1reg[i] = buf_load16(k_rs, k_off + 2u * k_half + i * k_half, 0);   // K(1): rows past Nk read as zeros
+  write_k(0);
+  write_v(0);
+#pragma unroll
+  for (int i = 0; i < NST; ++i) *reinterpret_cast<Vec16*>(&sm.k[1][(st_row + 32 * i) * K_LD + st_col]) = k1reg[i];
+  __syncthreads();
+""")
 kern = sub(kern, 'static_assert(WAVES == 4 || WAVES == 8, "4 or 8 waves per workgroup");',
            'static_assert(WAVES == 4 && LAZY && !EXP2, "the in-region experiment covers the default variant only");')
 head = cur[:cur.index("namespace {\n\n") + len("namespace {\n\n")]
