@@ -1,0 +1,25 @@
+"""Apply tools/r5_patches/*.patch to a scratch copy of the package sources and build the patched library NEXT TO the product's
+(tools/r5_patches/build/libelastic_hip_patched.so; the product tree is not touched).  Fails if a patch no longer applies.
+    python tools/r5_patches/build_patched.py"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from elasticdiffusion_official_amd import _hip   # noqa: E402
+
+out = os.path.join(HERE, "build", "libelastic_hip_patched.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+with tempfile.TemporaryDirectory() as tmp:
+    shutil.copytree(os.path.join(ROOT, "elasticdiffusion_official_amd", "csrc"), os.path.join(tmp, "elasticdiffusion_official_amd", "csrc"))
+    for p in sorted(glob.glob(os.path.join(HERE, "*.patch"))):
+        subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", p], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        print("applied", os.path.basename(p))
+    srcs = [os.path.join(tmp, "elasticdiffusion_official_amd", "csrc", os.path.basename(s)) for s in _hip.SOURCES]
+    subprocess.run(["hipcc", *_hip.HIPCC_FLAGS, "-I", _hip.INCLUDE, *srcs, "-o", out], check=True)
+print("built", out)
