@@ -313,16 +313,25 @@ class Block:
         return segs
 
     # ---- tools/gemm_sched: the same loop from a schedule descriptor (slot / pos of the 8 pieces, see gemm_sched.hip) -------------
+    def x_vo(self, wv, tile, h):
+        """gemm_sched.hip's x_vo: the lane addresses of m half h at K tile `tile` (convolution: the tap's pixel or the out-of-range sentinel)"""
+        if self.conv:
+            _, tap, ct = self.k_pos(tile)
+            dy, dx = tap // 3 - 1, tap - 3 * (tap // 3) - 1
+            delta = (dy * self.conv[1] + dx) * (self.K // 9 * 2) + ct * (BK * 2)
+            return np.where((wv.px_mask[h] >> tap) & 1, wv.x_voff[h] + delta, 0x80000000)
+        return wv.x_voff[h] + tile * (BK * 2)
+
     def piece(self, wv, bufi, tile, i, s1, s2):
         op, k = i >> 1, i & 1
         if op == 0:
             if s1:
                 rg = (wv.wave & 3) + 8 * (wv.wave >> 2) + 4
-                self.dma(wv, 0, (bufi ^ 1) * BUF + x_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.x_voff[1] + (tile + 1) * (BK * 2) + 64 * k, 0)
+                self.dma(wv, 0, (bufi ^ 1) * BUF + x_sub(0, 0) + rg * (2 * SUB) + k * SUB, self.x_vo(wv, tile + 1, 1) + 64 * k, 0)
         elif op == 2:
             if s2:
                 rg = (wv.wave & 3) + 8 * (wv.wave >> 2)
-                self.dma(wv, 0, bufi * BUF + x_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.x_voff[0] + (tile + 2) * (BK * 2) + 64 * k, 0)
+                self.dma(wv, 0, bufi * BUF + x_sub(0, 0) + rg * (2 * SUB) + k * SUB, self.x_vo(wv, tile + 2, 0) + 64 * k, 0)
         elif s2:
             g = 0 if op == 1 else 1
             rg = 8 * g + wv.wave
@@ -635,6 +644,12 @@ def main():
                         if not want_bad:
                             print(f"sched {name:>10s} M={M} K={K} ({K // BK} K tiles) N={N} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
                             bad += not ok
+            if name in ("product", "two_read"):      # the convolution runs these two (gemm_sched.hip: Conv<S_product>, Conv<S2_read>)
+                for (Bn, H, Wd, Cin, N) in [(2, 12, 12, 64, 128), (1, 9, 20, 128, 200)]:
+                    for mode in ("dma_early_read_late", "dma_late_read_early"):
+                        ok, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd), sched=name)
+                        print(f"sched {name:>10s} conv3x3 B={Bn} {H}x{Wd} Cin={Cin} N={N} {mode:>20s}: {'exact' if ok else 'WRONG'}")
+                        bad += not ok
             if want_bad:
                 print(f"sched {name}: replay", "caught the deliberately broken schedule" if caught else "DID NOT catch the broken schedule")
                 bad += not caught

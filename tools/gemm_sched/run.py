@@ -37,6 +37,7 @@ prod = _hip.lib()
 S = ctypes.CDLL(os.path.join(HERE, "libgemm_sched.so"))
 S.ed_s_geglu_gemm.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]
 S.ed_s_linear.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]
+S.ed_s_conv3x3_nhwc.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
 scheds = [int(v) for v in a.scheds.split(",")] if a.scheds else list(range(S.ed_s_count()))
 st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
 g = torch.Generator().manual_seed(0)
@@ -59,7 +60,19 @@ for (M, K, N) in [(81920, 640, 640), (81920, 640, 1920), (20480, 1280, 1280), (2
     cases.append((f"linear {M}x{K}->{N}", 2.0 * M * K * N, o,
                   lambda o, x=x, w=w, b=b, M=M, K=K, N=N: prod.ed_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, o.data_ptr(), 1, M, K, N, st()),
                   lambda s, o, x=x, w=w, b=b, M=M, K=K, N=N: S.ed_s_linear(s, x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), 1, M, K, N, st())))
-for name, flops, o, call_prod, call_s in cases:
+conv_cases = []
+for (B, H, W, Cin, N) in [(20, 32, 32, 1280, 1280), (20, 64, 64, 640, 640), (20, 128, 128, 320, 320), (6, 32, 32, 1280, 1280), (2, 12, 20, 64, 200)]:
+    cl = torch.channels_last
+    x = (torch.rand(B, Cin, H, W, generator=g) * 2 - 1).to("cuda", dt).contiguous(memory_format=cl)
+    w = ((torch.rand(N, Cin, 3, 3, generator=g) * 2 - 1) / (9 * Cin) ** 0.5).to("cuda", dt).contiguous(memory_format=cl)
+    b = (torch.rand(N, generator=g) * 2 - 1).to("cuda", dt)
+    o = [torch.empty(B, N, H, W, device="cuda", dtype=dt).contiguous(memory_format=cl) for _ in range(2)]
+    conv_cases.append((f"conv {B}x{H}x{W} {Cin}->{N} (bias only)", 2.0 * B * H * W * 9 * Cin * N, o,
+                       lambda o, x=x, w=w, b=b, B=B, H=H, W=W, Cin=Cin, N=N: prod.ed_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, o.data_ptr(), 1, B, H, W, Cin, N, st()),
+                       lambda s, o, x=x, w=w, b=b, B=B, H=H, W=W, Cin=Cin, N=N: S.ed_s_conv3x3_nhwc(s, x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), 1, B, H, W, Cin, N, st())))
+all_scheds = scheds
+for name, flops, o, call_prod, call_s in cases + conv_cases:
+    scheds = [s_ for s_ in all_scheds if s_ in (0, 6)] if name.startswith("conv") else all_scheds     # the convolution has two schedules
     o[0].zero_()
     assert call_prod(o[0]) == 0
     torch.cuda.synchronize()
