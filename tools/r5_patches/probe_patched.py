@@ -62,6 +62,12 @@ for (M, K, N, res) in [(81920, 640, 640, 0), (81920, 640, 640, 1), (81920, 640, 
     outs = [torch.empty(M, N, device="cuda", dtype=dt) for _ in range(2)]
     compare(f"ed_linear {M}x{K}->{N}{' + residual' if res else ''}",
             lambda L, o: L.ed_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, o.data_ptr(), 1, M, K, N, st()), outs, 2.0 * M * K * N)
+for (M, K, I) in [(20480, 1280, 5120), (81920, 640, 2560), (6144, 1280, 5120), (24576, 640, 2560), (300, 192, 256), (5000, 64, 128)]:     # 0003: persistent GEGLU
+    x = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).to(dt)
+    w = ((torch.rand(2 * I, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5).to(dt)
+    b = (torch.rand(2 * I, device="cuda", generator=g) * 2 - 1).to(dt)
+    outs = [torch.empty(M, I, device="cuda", dtype=dt) for _ in range(2)]
+    compare(f"ed_geglu_gemm {M}x{K}->{I}", lambda L, o: L.ed_geglu_gemm(x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), 1, M, K, I, st()), outs, 4.0 * M * K * I)
 for (B, H, W, Cin, N) in [(20, 32, 32, 1280, 1280), (2, 12, 20, 64, 200)]:     # convolution without addends (the upsampler's) takes the new path too
     cl = torch.channels_last
     x = (torch.rand(B, Cin, H, W, device="cuda", generator=g) * 2 - 1).to(dt).contiguous(memory_format=cl)
