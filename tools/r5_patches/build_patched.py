@@ -18,6 +18,8 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 with tempfile.TemporaryDirectory() as tmp:
     shutil.copytree(os.path.join(ROOT, "elasticdiffusion_official_amd", "csrc"), os.path.join(tmp, "elasticdiffusion_official_amd", "csrc"))
     for p in sorted(glob.glob(os.path.join(HERE, "*.patch"))):
+        if "-tests-" in os.path.basename(p):
+            continue      # (the scratch copy holds csrc/ only)
         subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", p], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
         print("applied", os.path.basename(p))
     srcs = [os.path.join(tmp, "elasticdiffusion_official_amd", "csrc", os.path.basename(s)) for s in _hip.SOURCES]
