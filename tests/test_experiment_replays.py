@@ -1,0 +1,32 @@
+"""CPU: the lane-level replays that stand behind the round-5 experiments (tools/gemm_persist, tools/gemm_sched, tools/attn16) keep
+passing -- they are what let those kernels run correctly on their first GPU launch, and what the patches in tools/r5_patches cite."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *args):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, cwd=ROOT)
+
+
+def test_persistent_gemm_prefetch_replay_and_its_broken_variant():
+    ok = _run("emulate_gemm_kernel.py", "--persist2")            # next tile's K tile 0 staged during the last K tile
+    assert ok.returncode == 0 and "WRONG" not in ok.stdout and ok.stdout.count("exact") >= 12, ok.stdout + ok.stderr
+    bad = _run("emulate_gemm_kernel.py", "--break", "pf")         # first prefetch aimed at the buffer being read
+    assert bad.returncode == 0 and "caught the deliberately broken schedule" in bad.stdout, bad.stdout + bad.stderr
+
+
+def test_schedule_descriptor_replays_including_the_convolution():
+    for name in ("two_read", "r4"):
+        ok = _run("emulate_gemm_kernel.py", "--sched", name)
+        assert ok.returncode == 0 and "WRONG" not in ok.stdout and "exact" in ok.stdout, ok.stdout + ok.stderr
+    assert "conv3x3" in _run("emulate_gemm_kernel.py", "--sched", "two_read").stdout
+    bad = _run("emulate_gemm_kernel.py", "--sched", "bad_early_b")
+    assert bad.returncode == 0 and "caught the deliberately broken schedule" in bad.stdout, bad.stdout + bad.stderr
+
+
+def test_attention_index_math_including_the_16x16x32_layout():
+    ok = _run("emulate_flash_attention.py")
+    assert ok.returncode == 0 and "index math OK" in ok.stdout and ok.stdout.count("16x16x32 experiment") == 3, ok.stdout + ok.stderr
