@@ -27,6 +27,13 @@ def test_schedule_descriptor_replays_including_the_convolution():
     assert bad.returncode == 0 and "caught the deliberately broken schedule" in bad.stdout, bad.stdout + bad.stderr
 
 
+def test_half_tile_mode_replay_and_its_broken_variant():
+    ok = _run("emulate_gemm_kernel.py", "--half")                 # value half only where a tile's gate half lies beyond N
+    assert ok.returncode == 0 and "WRONG" not in ok.stdout and ok.stdout.count("exact") >= 19, ok.stdout + ok.stderr
+    bad = _run("emulate_gemm_kernel.py", "--break", "half_raw")
+    assert bad.returncode == 0 and "caught the deliberately broken schedule" in bad.stdout, bad.stdout + bad.stderr
+
+
 def test_attention_index_math_including_the_16x16x32_layout():
     ok = _run("emulate_flash_attention.py")
     assert ok.returncode == 0 and "index math OK" in ok.stdout and ok.stdout.count("16x16x32 experiment") == 3, ok.stdout + ok.stderr

@@ -363,6 +363,18 @@ class Block:
             lambda: (issue(7), self.mma16(wv, 1, 0)),
         ]
 
+    def tile_segments_half(self, wv, bufi, tile, s1, s2):
+        """gemm_sched.hip's tile_phases_half: the value half only (a column tile whose gate half lies beyond N), 4 intervals per K tile"""
+        P = lambda i: self.piece(wv, bufi, tile, i, s1, s2)    # noqa: E731
+        return [
+            lambda: (self.read_w(wv, bufi, 0), self.read_x(wv, bufi, 0), P(0), P(1), self.wait_lgkm(wv, 0)),
+            lambda: self.mma16(wv, 0, 0),
+            lambda: (self.read_x(wv, bufi, 1), P(2), P(3), P(4), P(5),
+                     # BROKEN ON PURPOSE with 6 ("half_raw"): x m-half 1 of tile + 1 may not have landed when the tile ends
+                     self.wait_vm(wv, (6 if self.breakage == "half_raw" else 4) if s2 else 0), self.wait_lgkm(wv, 0)),
+            lambda: self.mma16(wv, 1, 0),
+        ]
+
     def retarget(self, wv, m0, n0):
         """tools/gemm_persist: the workgroup moves on to its next tile -- the addresses `setup()` recomputes, a fresh accumulator."""
         self.m0, self.n0 = m0, n0
@@ -424,6 +436,30 @@ class Block:
     def program(self, wv):
         nt = self.K // BK
         segs = []
+        if self.half_mode and self.epi == 1 and self.n0 + BN >= self.I:      # half tile: the gate half of this tile is beyond N
+            def prologue_half():
+                self.stage_w(wv, 0, 0, 0)
+                self.stage_x(wv, 0, 0, 0)
+                self.stage_x(wv, 0, 0, 1)
+                if nt > 1:
+                    self.stage_w(wv, 1, 1, 0)
+                    self.stage_x(wv, 1, 1, 0)
+                    self.wait_vm(wv, 4)
+                else:
+                    self.wait_vm(wv, 0)
+            segs.append(prologue_half)
+            if wv.wrow == 1:
+                segs.append(lambda: None)
+            t = 0
+            while t + 1 < nt:
+                segs += self.tile_segments_half(wv, 0, t, True, t + 2 < nt)
+                segs += self.tile_segments_half(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
+                t += 2
+            if t < nt:
+                segs += self.tile_segments_half(wv, 0, t, False, False)
+            if wv.wrow == 0:
+                segs.append(lambda: None)
+            return segs
 
         def prologue():
             self.stage_w(wv, 0, 0, 0)
@@ -479,6 +515,7 @@ class Block:
     pass_ = "all"
     flip = False
     sched = None
+    half_mode = False
 
     # ---- epilogue ---------------------------------------------------------------------------------------------------
     def epilogue(self, out_lin, out):
@@ -566,7 +603,7 @@ def gelu_as(x):
     return x - h if x > 0 else h
 
 
-def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False, sched=None):
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False, sched=None, half=False):
     """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K]); conv = (B, H, W): 3x3 convolution of an
     NHWC image with Cin = K / 9 as an implicit GEMM (M = B H W)."""
     rng = np.random.default_rng(seed)
@@ -596,6 +633,7 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
                     row_bias, residual, rps)
         blk.flip = flip
         blk.sched = sched
+        blk.half_mode = half
         blk.run()
         blk.epilogue(lin, out)
     assert len(seen) == nb, "workgroup remap is not a bijection"
@@ -622,12 +660,38 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early", "pf"], default=None)
+    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early", "pf", "half_raw"], default=None)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--persist", action="store_true", help="replay the persistent experiment (tools/gemm_persist) instead")
     ap.add_argument("--persist2", action="store_true", help="... its v2: the next tile's K tile 0 staged during the last K tile")
     ap.add_argument("--sched", default=None, help="replay a schedule descriptor of tools/gemm_sched (name, or 'all')")
+    ap.add_argument("--half", action="store_true", help="replay the half-tile mode of tools/gemm_sched (value half only where the gate half is beyond N)")
     a = ap.parse_args()
+    if a.breakage == "half_raw":
+        caught = 0
+        for mode in ("dma_early_read_late", "dma_late_read_early"):
+            try:
+                ok, _ = run_case(256, 448, 320, mode, breakage="half_raw", epi=1, half=True)
+            except AssertionError:
+                ok = False
+            caught += not ok
+        print("replay", "caught the deliberately broken schedule" if caught else "DID NOT catch the broken schedule")
+        sys.exit(0 if caught else 1)
+    if a.half:
+        bad = 0
+        for (M, K, N) in [(300, 256, 104), (256, 192, 320), (300, 448, 384), (256, 64, 640), (256, 128, 200)]:    # 200: no half tile (control)
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
+                    ok, _ = run_case(M, K, N, mode, flip, epi=1, half=True)
+                    print(f"half tiles M={M} K={K} ({K // BK} K tiles) N={N} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
+                    bad += not ok
+        for (Bn, H, Wd, Cin, N) in [(2, 12, 12, 64, 320), (1, 9, 20, 128, 104)]:
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                ok, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd), half=True)
+                ok2, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd), addends=True, seed=1, half=True)
+                print(f"half tiles conv3x3 B={Bn} {H}x{Wd} Cin={Cin} N={N} {mode:>20s}: {'exact' if ok else 'WRONG'}; with addends: {'exact' if ok2 else 'WRONG'}")
+                bad += (not ok) + (not ok2)
+        sys.exit(1 if bad else 0)
     if a.sched:
         bad = 0
         for name in (list(SCHEDS) if a.sched == "all" else [a.sched]):

@@ -11,6 +11,8 @@
 //             (R = the read half of a phase, pieces go behind its ds_reads; M = the MFMA half)
 //   pos[i]  = M slots: the piece goes in front of MFMA number pos (0..15), 16 = behind the last one
 //
+// Schedule 8 (EPI 1 only): the product order plus HALF tiles -- a column tile whose second 128-column half lies beyond N runs the value half
+// only (tile_phases_half; replay: emulate_gemm_kernel.py --half, --break half_raw is caught).
 // Convolutions (ed_s_conv3x3_nhwc: the product kernel's implicit-GEMM addresses through the same pieces) run the control and the 4-interval loop.
 // Same arithmetic in the same order for every schedule: results must be bit-identical to the product kernel's.  The counted waits
 // follow from the descriptor (in-order return): the wait at the end of R4 leaves the B / C / D pieces issued by then in flight
@@ -235,7 +237,34 @@ __device__ __forceinline__ void tile_phases_2(uint8_t* lds, const Ctx& c, Frags<
   ED_BARRIER();
 }
 
-template <class T, int EPI, class S, bool TWO>
+// ---- HALF: a column tile whose second 128-column half lies entirely beyond N (N mod 256 in (0, 128]: the last tile of N = 320, 640, 1920)
+// runs the value half only -- 256 x 128 outputs: no gate-row DMAs, no gate fragment reads, 32 instead of 64 MFMAs per K tile and wave.
+// 4 barrier intervals per K tile: R1 = W value + x m-half 0 (12 reads) and x m-half 1 of tile + 1; M1 = 16 MFMAs; R2 = x m-half 1 (8 reads),
+// W value rows and x m-half 0 of tile + 2, the tile's wait (those 4 pieces stay in flight); M2 = 16 MFMAs with the W fragments of R1.
+template <class T, int BUFI, bool CONV>
+__device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], TA a) {
+  read_w<T, BUFI, 0>(lds, c, f);
+  read_x<T, BUFI>(lds, c, f, 0);
+  piece<BUFI, 0, CONV>(lds, c, a);
+  piece<BUFI, 1, CONV>(lds, c, a);
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 0, 0>(acc, f);
+  ED_BARRIER();
+  read_x<T, BUFI>(lds, c, f, 1);
+  piece<BUFI, 2, CONV>(lds, c, a);
+  piece<BUFI, 3, CONV>(lds, c, a);
+  piece<BUFI, 4, CONV>(lds, c, a);
+  piece<BUFI, 5, CONV>(lds, c, a);
+  if (a.s2) wait_vm<4>();
+  else wait_vm<0>();
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 1, 0>(acc, f);
+  ED_BARRIER();
+}
+
+template <class T, int EPI, class S, bool TWO, bool HALF = false>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_sched(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
              uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w) {
@@ -300,6 +329,30 @@ k_gemm_sched(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
   const int nt = K / BK;
   const KPos p0 = {0, 0, 0};
   KPos pa = k_next<CONV>(p0, c.cpt), pb = k_next<CONV>(pa, c.cpt);     // positions of tiles t + 1, t + 2
+  const bool half = HALF && EPI == 1 && n0 + BN >= I;                  // wave-uniform: the gate half of this tile is beyond N
+  if (half) {
+    stage_w<0>(lds, c, 0, 0);
+    stage_x<0, CONV>(lds, c, p0, 0);
+    stage_x<0, CONV>(lds, c, p0, 1);
+    if (nt > 1) {
+      stage_w<1>(lds, c, 1, 0);
+      stage_x<1, CONV>(lds, c, pa, 0);
+      ED_WAIT_VM(4);
+    } else {
+      ED_WAIT_VM(0);
+    }
+    ED_BARRIER();
+    if (wrow == 1) ED_BARRIER();
+    int th = 0;
+    for (; th + 1 < nt; th += 2) {
+      tile_phases_half<T, 0, CONV>(lds, c, f, acc, TA{th, true, th + 2 < nt, pa, pb});
+      pa = pb, pb = k_next<CONV>(pb, c.cpt);
+      tile_phases_half<T, 1, CONV>(lds, c, f, acc, TA{th + 1, th + 2 < nt, th + 3 < nt, pa, pb});
+      pa = pb, pb = k_next<CONV>(pb, c.cpt);
+    }
+    if (th < nt) tile_phases_half<T, 0, CONV>(lds, c, f, acc, TA{th, false, false, pa, pb});
+    if (wrow == 0) ED_BARRIER();
+  } else {
   stage_w<0>(lds, c, 0, 0);
   stage_x<0, CONV>(lds, c, p0, 0);
   stage_w<0>(lds, c, 0, 1);
@@ -344,6 +397,7 @@ k_gemm_sched(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, con
     if (t < nt) tile_phases_s<T, 0, S, false>(lds, c, f, acc, TA{t, false, false, pa, pb});
   }
   if (wrow == 0) ED_BARRIER();
+  }   // (!half)
   if (S::slot[7] == 7 || (TWO && S::slot[7] == 3)) wait_vm<0>();   // (nothing is in flight here: s2 was false for the last two tiles)
 
   float bv[2][4], bg[2][4];
@@ -397,10 +451,19 @@ int launch_sched(int sched, const void* x, const void* w, const void* bias, void
 #define ED_GO(SS, TWO_)                                                                                                            \
   k_gemm_sched<HF, EPI, SS, TWO_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, \
                                                         (int)M, K, I, nbn, (int)nb, img_h, img_w)
-  if (CONV) {      // the convolution runs the control (product order) and the 4-interval loop
+#define ED_GO_HALF(SS)                                                                                                             \
+  k_gemm_sched<HF, EPI, SS, false, true><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, \
+                                                              (int)M, K, I, nbn, (int)nb, img_h, img_w)
+  if (CONV) {      // the convolution runs the control (product order), the 4-interval loop and the control with half tiles
     if (sched == 0) ED_GO(Conv<S_product>, false);
     else if (sched == 6) ED_GO(Conv<S2_read>, true);
+    else if (sched == 8) ED_GO_HALF(Conv<S_product>);
     else return bad;
+    return (int)hipGetLastError();
+  }
+  if (sched == 8) {   // product order; a last column tile with nothing in its second half runs the value half only
+    if (EPI != 1) return bad;
+    ED_GO_HALF(S_product);
     return (int)hipGetLastError();
   }
   switch (sched) {
@@ -431,5 +494,5 @@ int ed_s_linear(int sched, const void* x, const void* w, const void* bias, void*
 int ed_s_conv3x3_nhwc(int sched, const void* x, const void* w, const void* bias, void* out, int dtype, int B, int H, int W, int Cin, int N, void* stream) {
   return launch_sched<1, true>(sched, x, w, bias, out, dtype, (int64_t)B * H * W, 9 * Cin, N, stream, H, W);
 }
-int ed_s_count(void) { return 8; }
+int ed_s_count(void) { return 8; }   // (schedule 8 = half tiles: EPI 1 only, not part of the sweep)
 }

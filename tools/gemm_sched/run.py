@@ -14,7 +14,7 @@ import torch
 from elasticdiffusion_official_amd import _hip
 
 _vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
-NAMES = ["product_order", "late", "mid", "spread", "mfma_all", "r4", "two_read", "two_mfma"]
+NAMES = ["product_order", "late", "mid", "spread", "mfma_all", "r4", "two_read", "two_mfma", "half_tiles"]
 
 
 def timed(fn, n=10):
@@ -52,7 +52,7 @@ for (M, K, I) in [(20480, 1280, 5120), (81920, 640, 2560), (6144, 1280, 5120), (
                   lambda o, x=x, w=w, b=b, M=M, K=K, I=I: prod.ed_geglu_gemm(x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), 1, M, K, I, st()),
                   lambda s, o, x=x, w=w, b=b, M=M, K=K, I=I: S.ed_s_geglu_gemm(s, x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), 1, M, K, I, st())))
 for (M, K, N) in [(81920, 640, 640), (81920, 640, 1920), (20480, 1280, 1280), (20480, 1280, 3840), (20480, 5120, 1280), (8192, 8192, 8192),
-                  (1000, 320, 200), (2000, 448, 520), (500, 64, 256), (700, 128, 300)]:
+                  (81920, 2560, 640), (327680, 640, 320), (327680, 960, 320), (1000, 320, 200), (2000, 448, 520), (500, 64, 256), (700, 128, 304), (300, 256, 104)]:
     x = (torch.rand(M, K, generator=g) * 2 - 1).to("cuda", dt)
     w = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to("cuda", dt)
     b = (torch.rand(N, generator=g) * 2 - 1).to("cuda", dt)
@@ -73,6 +73,8 @@ for (B, H, W, Cin, N) in [(20, 32, 32, 1280, 1280), (20, 64, 64, 640, 640), (20,
 all_scheds = scheds
 for name, flops, o, call_prod, call_s in cases + conv_cases:
     scheds = [s_ for s_ in all_scheds if s_ in (0, 6)] if name.startswith("conv") else all_scheds     # the convolution has two schedules
+    if not name.startswith("geglu") and not a.scheds:      # + the half-tile mode (value half only where the gate half is beyond N)
+        scheds = scheds + [8]
     o[0].zero_()
     assert call_prod(o[0]) == 0
     torch.cuda.synchronize()

@@ -54,7 +54,8 @@ def compare(name, call, outs, flops, rounds=a.rounds):
 
 
 dt = torch.float16
-for (M, K, N, res) in [(81920, 640, 640, 0), (81920, 640, 640, 1), (81920, 640, 1920, 0), (20480, 1280, 1280, 0), (20480, 2560, 640, 1), (1000, 320, 200, 0), (700, 128, 304, 1)]:
+for (M, K, N, res) in [(81920, 640, 640, 0), (81920, 640, 640, 1), (81920, 640, 1920, 0), (20480, 1280, 1280, 0), (20480, 2560, 640, 1), (1000, 320, 200, 0), (700, 128, 304, 1),
+                       (327680, 640, 320, 0), (81920, 2560, 640, 0), (300, 256, 104, 1), (600, 64, 384, 0)]:     # N mod 256 in (0, 128]: 0005's half tiles
     x = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).to(dt)
     w = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) / K ** 0.5).to(dt)
     b = (torch.rand(N, device="cuda", generator=g) * 2 - 1).to(dt)
@@ -68,7 +69,7 @@ for (M, K, I) in [(20480, 1280, 5120), (81920, 640, 2560), (6144, 1280, 5120), (
     b = (torch.rand(2 * I, device="cuda", generator=g) * 2 - 1).to(dt)
     outs = [torch.empty(M, I, device="cuda", dtype=dt) for _ in range(2)]
     compare(f"ed_geglu_gemm {M}x{K}->{I}", lambda L, o: L.ed_geglu_gemm(x.data_ptr(), w.data_ptr(), b.data_ptr(), o.data_ptr(), 1, M, K, I, st()), outs, 4.0 * M * K * I)
-for (B, H, W, Cin, N) in [(20, 32, 32, 1280, 1280), (2, 12, 20, 64, 200)]:     # convolution without addends (the upsampler's) takes the new path too
+for (B, H, W, Cin, N) in [(20, 32, 32, 1280, 1280), (2, 12, 20, 64, 200), (20, 128, 128, 320, 320), (20, 64, 64, 640, 640), (2, 12, 20, 64, 104)]:     # without addends (the upsampler's); 320 / 640 / 104: half tiles
     cl = torch.channels_last
     x = (torch.rand(B, Cin, H, W, device="cuda", generator=g) * 2 - 1).to(dt).contiguous(memory_format=cl)
     w = ((torch.rand(N, Cin, 3, 3, device="cuda", generator=g) * 2 - 1) / (9 * Cin) ** 0.5).to(dt).contiguous(memory_format=cl)
@@ -76,6 +77,17 @@ for (B, H, W, Cin, N) in [(20, 32, 32, 1280, 1280), (2, 12, 20, 64, 200)]:     #
     outs = [torch.empty(B, N, H, W, device="cuda", dtype=dt).contiguous(memory_format=cl) for _ in range(2)]
     compare(f"ed_conv3x3_nhwc {B}x{H}x{W} {Cin}->{N} (bias only)",
             lambda L, o: L.ed_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, None, o.data_ptr(), 1, B, H, W, Cin, N, st()), outs, 2.0 * B * H * W * 9 * Cin * N)
+for (B, H, W, Cin, N) in [(20, 128, 128, 320, 320), (6, 64, 64, 640, 640), (2, 9, 20, 128, 104)]:     # the ResnetBlock form: per-sample bias + residual, half tiles
+    cl = torch.channels_last
+    x = (torch.rand(B, Cin, H, W, device="cuda", generator=g) * 2 - 1).to(dt).contiguous(memory_format=cl)
+    w = ((torch.rand(N, Cin, 3, 3, device="cuda", generator=g) * 2 - 1) / (9 * Cin) ** 0.5).to(dt).contiguous(memory_format=cl)
+    b = (torch.rand(N, device="cuda", generator=g) * 2 - 1).to(dt)
+    sb = (torch.rand(B, N, device="cuda", generator=g) * 2 - 1).to(dt)
+    rs = (torch.rand(B, N, H, W, device="cuda", generator=g) * 2 - 1).to(dt).contiguous(memory_format=cl)
+    outs = [torch.empty(B, N, H, W, device="cuda", dtype=dt).contiguous(memory_format=cl) for _ in range(2)]
+    compare(f"ed_conv3x3_nhwc {B}x{H}x{W} {Cin}->{N} (+ per-sample bias + residual)",
+            lambda L, o: L.ed_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), b.data_ptr(), sb.data_ptr(), rs.data_ptr(), o.data_ptr(), 1, B, H, W, Cin, N, st()), outs,
+            2.0 * B * H * W * 9 * Cin * N)
 for dtt, code in ((torch.float16, 1), (torch.bfloat16, 2)):
     for (B, H, Nq, Nk, vps) in [(20, 10, 4096, 4096, (5,)), (20, 20, 1024, 1024, (5, 4)), (6, 20, 1024, 1024, (5,)), (2, 3, 200, 333, (4, 5, 7, 9, 10)), (1, 2, 256, 128, (4, 5, 9, 10)),
                                 (1, 2, 130, 64, (4, 5))]:
