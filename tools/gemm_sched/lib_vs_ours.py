@@ -18,6 +18,7 @@ from elasticdiffusion_official_amd import _hip
 _vp, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--patched", action="store_true", help="add an arm for tools/r5_patches/build/libelastic_hip_patched.so (ed_linear)")
 a = ap.parse_args()
 prod = _hip.lib()
 S = ctypes.CDLL(os.path.join(HERE, "libgemm_sched.so"))
@@ -25,6 +26,10 @@ S.ed_s_linear.argtypes = [_i, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]
 P = ctypes.CDLL(os.path.join(os.path.dirname(HERE), "gemm_persist", "libgemm_persist.so"))
 P.ed_p_linear.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]
 P.ed_p2_linear.argtypes = P.ed_p_linear.argtypes
+PAT = None
+if a.patched:
+    PAT = ctypes.CDLL(os.path.join(os.path.dirname(HERE), "r5_patches", "build", "libelastic_hip_patched.so"))
+    PAT.ed_linear.argtypes = _hip.SIGNATURES["ed_linear"]
 st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
 g = torch.Generator().manual_seed(0)
 dt = torch.float16
@@ -72,6 +77,8 @@ for (M, K, N, calls) in shapes:
         "persistent_v1": lambda: P.ed_p_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, o.data_ptr(), 1, M, K, N, 256, st()),
         "persistent_v2": lambda: P.ed_p2_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, o.data_ptr(), 1, M, K, N, 256, st()),
     }
+    if PAT is not None:
+        arms["patched_library"] = lambda: PAT.ed_linear(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, o.data_ptr(), 1, M, K, N, st())
     timers = {k: graphed(f) for k, f in arms.items()}
     err = float((o.float() - ref.float()).abs().max())
     ts = {k: [] for k in arms}
