@@ -679,7 +679,8 @@ def main():
         sys.exit(0 if caught else 1)
     if a.half:
         bad = 0
-        for (M, K, N) in [(300, 256, 104), (256, 192, 320), (300, 448, 384), (256, 64, 640), (256, 128, 200)]:    # 200: no half tile (control)
+        for (M, K, N) in [(300, 256, 104), (256, 192, 320), (300, 448, 384), (256, 64, 640), (256, 128, 200),      # 200: no half tile (control)
+                           (256, 64, 320), (256, 128, 320), (300, 320, 104), (256, 512, 320)][:None if not a.quick else 3]:    # 1, 2, 5, 8 K tiles
             for mode in ("dma_early_read_late", "dma_late_read_early"):
                 for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
                     ok, _ = run_case(M, K, N, mode, flip, epi=1, half=True)
