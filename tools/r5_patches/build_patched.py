@@ -1,6 +1,6 @@
 """Apply tools/r5_patches/*.patch to a scratch copy of the package sources and build the patched library NEXT TO the product's
 (tools/r5_patches/build/libelastic_hip_patched.so; the product tree is not touched).  Fails if a patch no longer applies.
-    python tools/r5_patches/build_patched.py"""
+    python tools/r5_patches/build_patched.py [--only 0001,0003] [--out NAME.so]      # a subset (in order) / another file name under build/"""
 import glob
 import os
 import shutil
@@ -13,13 +13,26 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from elasticdiffusion_official_amd import _hip   # noqa: E402
 
-out = os.path.join(HERE, "build", "libelastic_hip_patched.so")
+only = None
+name = "libelastic_hip_patched.so"
+argv = sys.argv[1:]
+while argv:
+    flag = argv.pop(0)
+    if flag == "--only":
+        only = argv.pop(0).split(",")
+    elif flag == "--out":
+        name = argv.pop(0)
+    else:
+        raise SystemExit(f"unknown argument {flag}")
+out = os.path.join(HERE, "build", name)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with tempfile.TemporaryDirectory() as tmp:
     shutil.copytree(os.path.join(ROOT, "elasticdiffusion_official_amd", "csrc"), os.path.join(tmp, "elasticdiffusion_official_amd", "csrc"))
     for p in sorted(glob.glob(os.path.join(HERE, "*.patch"))):
         if "-tests-" in os.path.basename(p):
             continue      # (the scratch copy holds csrc/ only)
+        if only is not None and os.path.basename(p)[:4] not in only:
+            continue
         subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", p], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
         print("applied", os.path.basename(p))
     srcs = [os.path.join(tmp, "elasticdiffusion_official_amd", "csrc", os.path.basename(s)) for s in _hip.SOURCES]

@@ -15,9 +15,10 @@ from elasticdiffusion_official_amd import _hip
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--lib", default="libelastic_hip_patched.so", help="file under tools/r5_patches/build/ (build_patched.py --only ... --out ...)")
 a = ap.parse_args()
 prod = _hip.lib()
-pat = ctypes.CDLL(os.path.join(HERE, "build", "libelastic_hip_patched.so"))
+pat = ctypes.CDLL(os.path.join(HERE, "build", a.lib))
 for name in ("ed_linear", "ed_geglu_gemm", "ed_conv3x3_nhwc", "ed_flash_attention"):
     getattr(pat, name).argtypes = _hip.SIGNATURES[name]
     getattr(pat, name).restype = ctypes.c_int
