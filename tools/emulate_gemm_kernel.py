@@ -387,8 +387,10 @@ class Block:
         prologue DMAs are issued in the interval that follows the barrier pair ending the current tile (before its epilogue, which
         touches no LDS), and waited for at the top of the next tile exactly like a fresh workgroup's."""
         nt = self.K // BK
-        early_start = nt >= 3
+        two = bool(self.sched) and SCHEDS[self.sched][2]     # the 4-interval loop inside the persistent one (r5_patches/0006: no early start)
+        early_start = nt >= 3 and not two
         prefetch = v2 and nt >= 6 and nt % 2 == 0      # v2: the last K tile (buffer 1) stages the next tile's K tile 0 into buffer 0
+        assert not (two and v2)
         segs = []
 
         def issue(j):
@@ -417,12 +419,17 @@ class Block:
                 segs.append(lambda: None)
             t = 0
             while t + 1 < nt:
+                if two:
+                    segs += self.tile_segments_sched(wv, 0, t, True, t + 2 < nt, sched=self.sched)
+                    segs += self.tile_segments_sched(wv, 1, t + 1, t + 2 < nt, t + 3 < nt, sched=self.sched)
+                    t += 2
+                    continue
                 segs += self.tile_segments(wv, 0, t, True, t + 2 < nt, first=(t == 0 and early_start))
                 pfn = prefetch and t + 2 == nt and j + 1 < len(tiles)
                 segs += self.tile_segments_b1(wv, t + 1, t + 2 < nt, t + 3 < nt, tiles[j + 1] if pfn else None)
                 t += 2
             if t < nt:
-                segs += self.tile_segments(wv, 0, t, False, False)
+                segs += self.tile_segments_sched(wv, 0, t, False, False, sched=self.sched) if two else self.tile_segments(wv, 0, t, False, False)
             if wv.wrow == 0:
                 segs.append(lambda: None)
         segs.append(lambda: wv.done.append((self.m0_of[wv.wave], self.n0_of[wv.wave], wv.acc.copy())) if self.pass_ != "rest" else None)
@@ -549,7 +556,7 @@ class Block:
                                     out_lin[m[l], col] = v
 
 
-def run_persist_case(M, K, N, mode, G, flip=False, seed=0, v2=False, breakage=None):
+def run_persist_case(M, K, N, mode, G, flip=False, seed=0, v2=False, breakage=None, sched=None):
     """Plain projection through the persistent variant with a grid of G workgroups (tile ids b, b + G, ...)."""
     rng = np.random.default_rng(seed)
     x = rng.integers(-4, 5, size=(M, K)).astype(np.float64)
@@ -574,6 +581,7 @@ def run_persist_case(M, K, N, mode, G, flip=False, seed=0, v2=False, breakage=No
         seen.update(tiles)
         blk = Block(x, w, bias, M, K, N, tiles[0][0], tiles[0][1], mode, breakage, 1, None)
         blk.flip = flip
+        blk.sched = sched
         blk.run_persist(tiles, v2)
         for wv in blk.waves:
             assert len(wv.done) == len(tiles)
@@ -663,6 +671,7 @@ def main():
     ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early", "pf", "half_raw"], default=None)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--persist", action="store_true", help="replay the persistent experiment (tools/gemm_persist) instead")
+    ap.add_argument("--sched-in-persist", action="store_true", help="with --persist: the 4-interval K loop inside the persistent loop")
     ap.add_argument("--persist2", action="store_true", help="... its v2: the next tile's K tile 0 staged during the last K tile")
     ap.add_argument("--sched", default=None, help="replay a schedule descriptor of tools/gemm_sched (name, or 'all')")
     ap.add_argument("--half", action="store_true", help="replay the half-tile mode of tools/gemm_sched (value half only where the gate half is beyond N)")
@@ -721,6 +730,15 @@ def main():
         sys.exit(1 if bad else 0)
     if a.breakage == "pf":
         a.persist2 = True
+    if a.persist and a.sched_in_persist:       # the persistent loop around the 4-interval K loop (r5_patches/0006)
+        bad = 0
+        for (M, K, N, G) in [(768, 192, 768, 4), (512, 256, 512, 3), (300, 64, 640, 2), (512, 448, 512, 3)]:
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
+                    ok = run_persist_case(M, K, N, mode, G, flip, sched="two_read")
+                    print(f"persistent + 4-interval loop M={M} K={K} ({K // BK} K tiles) N={N} grid {G} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
+                    bad += not ok
+        sys.exit(1 if bad else 0)
     if a.persist or a.persist2:
         bad = 0
         shapes = [(768, 192, 768, 4), (512, 256, 512, 3), (300, 64, 640, 2)]

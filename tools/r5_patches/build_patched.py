@@ -33,6 +33,8 @@ with tempfile.TemporaryDirectory() as tmp:
             continue      # (the scratch copy holds csrc/ only)
         if only is not None and os.path.basename(p)[:4] not in only:
             continue
+        if only is None and os.path.basename(p).startswith("0006"):
+            continue      # optional: probe it first (--only 0001,0003,0005,0006 --out ...)
         subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", p], cwd=tmp, check=True, stdout=subprocess.DEVNULL)
         print("applied", os.path.basename(p))
     srcs = [os.path.join(tmp, "elasticdiffusion_official_amd", "csrc", os.path.basename(s)) for s in _hip.SOURCES]
