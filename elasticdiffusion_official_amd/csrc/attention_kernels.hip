@@ -532,8 +532,10 @@ __device__ __forceinline__ void resoftmax_tile(const uint16_t* kt, int ln, int h
 // latency for a 16-byte read under load -- every MFMA waits for its operand, which is what holds SQ_VALU_MFMA_BUSY at 0.41
 // whatever the VALU count (v_path 4 / 5 / 6 within 1 % of each other inside the UNet).  DEPTH 3 keeps three reads in flight
 // (+8 VGPRs for the ring).
-template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY, bool EXP2, int DEPTH>
-__device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16_t* v_prev, int lane, int ln, int hi,
+// `filler(i)` is issued behind MFMA slot i (the next tiles' global loads and LDS writes: VMEM / DS instructions co-issue with the MFMA and
+// VALU stream here, while in front of and behind the region they stood alone -- tools/attn16: +0.4...4.2 %, bit-identical)
+template <typename T, bool HAS_PV, bool HAS_NEXT, bool LAZY, bool EXP2, int DEPTH, class Filler>
+__device__ __forceinline__ void pipe_region(Filler&& filler, const uint16_t* k_next, const uint16_t* v_prev, int lane, int ln, int hi,
                                             const typename T::v8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
                                             const typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4],
                                             f32x16 (&o)[2], float sl, SoftmaxRun& run, const f32x16& negm) {
@@ -570,6 +572,7 @@ __device__ __forceinline__ void pipe_region(const uint16_t* k_next, const uint16
     }
     if (LAZY) softmax_slice_lazy<T, EXP2>(i, s_cur, sl, run, p_cur);
     else softmax_slice<T>(i, s_cur, sl, run, p_cur);
+    filler(i);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -652,14 +655,16 @@ k_flash_attn_pipe(const Params p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
+  // prologue: K(0), V(0) and K(1) in flight together (K(1) past the end reads as zeros into a buffer nobody reads)
   load_k(0);
   load_v(0);
+  Vec16 k1reg[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) k1reg[i] = buf_load16(k_rs, k_off + 2u * k_half + i * k_half, 0);
   write_k(0);
   write_v(0);
-  if (n_tiles > 1) {
-    load_k(1);
-    write_k(1);
-  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) *reinterpret_cast<Vec16*>(&sm.k[1][(st_row + 32 * i) * K_LD + st_col]) = k1reg[i];
   __syncthreads();
 
   // ping-pong register sets (named, statically indexed: no copies between iterations)
@@ -671,11 +676,22 @@ k_flash_attn_pipe(const Params p) {
   // one full (unmasked) tile t: S_cur holds K(t) Q^T on entry
   auto iter = [&](auto has_pv, auto has_next, int t, f32x16 (&s_cur)[2], f32x16 (&s_next)[2],
                   typename T::v8 (&p_prev)[4], typename T::v8 (&p_cur)[4]) {
-    load_k(t + 2);  // unconditional: a tile past the end reads as zeros (buffer bounds check) into a buffer nobody reads
-    load_v(t + 1);
+    // the next tiles' global loads (K(t+2), V(t+1): unconditional, a tile past the end reads as zeros into a buffer nobody reads) go behind
+    // MFMA slots 0 .. 2 NST - 1 of the region, their LDS writes behind slots 11 .. 11 + 2 NST - 1 (both target buffers are idle during the
+    // iteration: K(t-1)'s and V(t-2)'s)
+    const uint32_t kbase = k_off + (uint32_t)(t + 2) * 2u * k_half, vbase = v_off + (uint32_t)(t + 1) * 2u * v_half;
+    uint16_t* const kdst = sm.k[kb_write];
+    uint16_t* const vdst = sm.v[vb_next];
+    auto filler = [&](int i) {
+      if (i < NST) kreg[i] = buf_load16(k_rs, kbase + i * k_half, 0);
+      else if (i < 2 * NST) vreg[i - NST] = buf_load16(v_rs, vbase + (i - NST) * v_half, 0);
+      else if (i >= 11 && i < 11 + NST) *reinterpret_cast<Vec16*>(&kdst[(st_row + 32 * (i - 11)) * K_LD + st_col]) = kreg[i - 11];
+      else if (i >= 11 + NST && i < 11 + 2 * NST)
+        *reinterpret_cast<Vec16*>(&vdst[(st_row + 32 * (i - 11 - NST)) * V_LD_TR + st_col]) = vreg[i - 11 - NST];
+    };
     // the first tile (no PV yet) takes the exact softmax; EXP2 found its maximum before the loop and is lazy throughout
     constexpr bool lazy = LAZY && (EXP2 || decltype(has_pv)::value);
-    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2, DEPTH>(sm.k[kb_next], sm.v[vb_prev], lane, ln,
+    pipe_region<T, decltype(has_pv)::value, decltype(has_next)::value, lazy, EXP2, DEPTH>(filler, sm.k[kb_next], sm.v[vb_prev], lane, ln,
                                                                                           hi, qf, s_cur, s_next, p_prev, p_cur,
                                                                                           oacc, sl, run, negm);
     if (lazy) {
@@ -703,8 +719,6 @@ k_flash_attn_pipe(const Params p) {
         oacc[1][i] *= run.alpha;
       }
     }
-    write_k(kb_write);
-    write_v(vb_next);
     const int tmp = vb_prev;
     vb_prev = vb_cur, vb_cur = vb_next, vb_next = tmp;
     const int ktmp = kb_cur;  // two buffers: (cur, next, write) = (a, b, a) -> (b, a, b); three: a rotation

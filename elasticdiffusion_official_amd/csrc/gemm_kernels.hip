@@ -252,6 +252,41 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   ED_BARRIER();
 }
 
+// HALF tile (round 5): a column tile of the plain projection / convolution whose second 128-column half lies entirely beyond the output
+// width (N mod 256 in (0, 128]: the last tile of N = 320, 640, 1920) runs the first half only -- 256 x 128 outputs: no DMAs and no
+// fragment reads for the second half's W rows, 32 instead of 64 MFMAs per K tile and wave (those 32 multiplied zero-filled rows and
+// their results were never stored: 25 % of the N = 320 convolutions' MFMAs, 17 % at N = 640).  Four barrier intervals per K tile:
+//   R1  W rows + x m-half 0 (12 fragment reads); x m-half 1 of tile + 1 -> the other buffer (its copy was last read in the previous R2)
+//   M1  16 MFMAs (m half 0)
+//   R2  x m-half 1 (8 reads); W rows and x m-half 0 of tile + 2 -> this buffer (both last read in R1, by either wave row one interval ago);
+//       vmcnt(4): all of tile + 1 has landed, those two half tiles stay in flight
+//   M2  16 MFMAs (m half 1, the W fragments of R1)
+// A wave retires its fragment reads before its barrier (the other wave row is busy with 16 MFMAs meanwhile).  Replayed under both
+// adversarial timings in tools/emulate_gemm_kernel.py --half (--break half_raw weakens the count and is caught).
+template <class T, int BUFI, bool CONV>
+__device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1, bool s2,
+                                                 KPos p1, KPos p2) {
+  read_w<T, BUFI, 0>(lds, c, f);
+  read_x<T, BUFI>(lds, c, f, 0);
+  if (s1) stage_x<BUFI ^ 1, CONV>(lds, c, p1, 1);
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 0, 0>(acc, f);
+  ED_BARRIER();
+  read_x<T, BUFI>(lds, c, f, 1);
+  if (s2) {
+    stage_w<BUFI>(lds, c, tile + 2, 0);
+    stage_x<BUFI, CONV>(lds, c, p2, 0);
+    ED_WAIT_VM(4);
+  } else {
+    ED_WAIT_VM(0);
+  }
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 1, 0>(acc, f);
+  ED_BARRIER();
+}
+
 // EPI 0: GEGLU -- W is [2 I, K], the two 128-row halves of the tile are value rows n0.. and gate rows I + n0.., out is [M, I]
 // EPI 1: plain projection + bias -- W is [I, K] (I = output columns), the halves are rows n0.. and n0 + 128.., out is [M, I];
 //        the same main loop, kept so that the schedule can be timed against hipBLASLt on every projection of the block
@@ -261,7 +296,9 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
 // Plain-projection epilogue extras (EPI 1; each optional): row_bias [M / rows_per_sample, I] is added to every row of its sample
 // (ResnetBlock2D's time-embedding add), residual [M, I] element-wise (the block's closing residual / a transformer's skip):
 //     out = round16(acc + bias[n] + row_bias[m / rows_per_sample, n] + residual[m, n])        one rounding, fp32 sums
-template <class T, int EPI, bool CONV>
+// ADD (EPI 1): the launch has at least one epilogue addend (row_bias / residual).  Without the flag the epilogue converted and added two
+// pairs of zero vectors per store even when both pointers were null: 1.7-3.7 % of a plain projection (profiles/r4_s15_*, r4_s17_*).
+template <class T, int EPI, bool CONV, bool ADD = true>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
               const uint16_t* __restrict__ row_bias, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int M,
@@ -347,6 +384,32 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   const KPos p0 = {0, 0, 0};
   KPos pa = k_next<CONV>(p0, c.cpt);      // position of tile t + 1
   KPos pb = k_next<CONV>(pa, c.cpt);      // position of tile t + 2
+  const bool half = EPI == 1 && n0 + BN >= I;     // wave-uniform: nothing of this tile's second half is inside the output (tile_phases_half)
+  if (half) {
+    stage_w<0>(lds, c, 0, 0);
+    stage_x<0, CONV>(lds, c, p0, 0);
+    stage_x<0, CONV>(lds, c, p0, 1);
+    if (nt > 1) {
+      stage_w<1>(lds, c, 1, 0);
+      stage_x<1, CONV>(lds, c, pa, 0);
+      ED_WAIT_VM(4);              // all of tile 0 (6 DMAs); tile 1's two half tiles stay in flight
+    } else {
+      ED_WAIT_VM(0);
+    }
+    ED_BARRIER();
+    if (wrow == 1) ED_BARRIER();
+    int th = 0;
+    for (; th + 1 < nt; th += 2) {
+      tile_phases_half<T, 0, CONV>(lds, c, f, acc, th, true, th + 2 < nt, pa, pb);
+      pa = pb;
+      pb = k_next<CONV>(pb, c.cpt);
+      tile_phases_half<T, 1, CONV>(lds, c, f, acc, th + 1, th + 2 < nt, th + 3 < nt, pa, pb);
+      pa = pb;
+      pb = k_next<CONV>(pb, c.cpt);
+    }
+    if (th < nt) tile_phases_half<T, 0, CONV>(lds, c, f, acc, th, false, false, pa, pb);
+    if (wrow == 0) ED_BARRIER();
+  } else {
   stage_w<0>(lds, c, 0, 0);
   stage_x<0, CONV>(lds, c, p0, 0);
   stage_w<0>(lds, c, 0, 1);
@@ -384,6 +447,7 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   }
   if (t < nt) tile_phases<T, 0, CONV>(lds, c, f, acc, t, false, false, pa, pb);
   if (wrow == 0) ED_BARRIER();    // pair the extra barrier of the second wave row
+  }   // (!half)
 
   // epilogue: one 16-byte store per (lane, 16-row block): 8 consecutive columns of one row
   float bv[2][4], bg[2][4];
@@ -410,12 +474,12 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
       const bool ok_v = m < M && ncol < I, ok_g = m < M && ncol + gap < I;
       // the (optional) addends of this row's two 8-column groups: 16-byte loads, zeros when absent / out of range
       u32x4 av[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, ag[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
-      if (row_bias) {
+      if (ADD && row_bias) {
         const int64_t rb = (int64_t)(m / rows_per_sample) * I;
         if (ok_v) av[0] = *reinterpret_cast<const u32x4*>(row_bias + rb + ncol);
         if (ok_g) ag[0] = *reinterpret_cast<const u32x4*>(row_bias + rb + ncol + gap);
       }
-      if (residual) {
+      if (ADD && residual) {
         if (ok_v) av[1] = *reinterpret_cast<const u32x4*>(residual + (int64_t)m * I + ncol);
         if (ok_g) ag[1] = *reinterpret_cast<const u32x4*>(residual + (int64_t)m * I + ncol + gap);
       }
@@ -424,10 +488,12 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
       for (int e = 0; e < 8; e += 2) {   // column e of the group = fragment e >> 2, accumulator register e & 3
         float v0 = acc[mb][e >> 2][e & 3] + bv[e >> 2][e & 3], v1 = acc[mb][e >> 2][(e & 3) + 1] + bv[e >> 2][(e & 3) + 1];
         float g0 = acc[mb][2 + (e >> 2)][e & 3] + bg[e >> 2][e & 3], g1 = acc[mb][2 + (e >> 2)][(e & 3) + 1] + bg[e >> 2][(e & 3) + 1];
+        if (ADD) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          v0 += T::to_f32((uint16_t)av[a][e >> 1]), v1 += T::to_f32((uint16_t)(av[a][e >> 1] >> 16));
-          g0 += T::to_f32((uint16_t)ag[a][e >> 1]), g1 += T::to_f32((uint16_t)(ag[a][e >> 1] >> 16));
+          for (int a = 0; a < 2; ++a) {
+            v0 += T::to_f32((uint16_t)av[a][e >> 1]), v1 += T::to_f32((uint16_t)(av[a][e >> 1] >> 16));
+            g0 += T::to_f32((uint16_t)ag[a][e >> 1]), g1 += T::to_f32((uint16_t)(ag[a][e >> 1] >> 16));
+          }
         }
         pv[e >> 1] = (uint32_t)T::from_f32(v0) | ((uint32_t)T::from_f32(v1) << 16);
         pg[e >> 1] = (uint32_t)T::from_f32(g0) | ((uint32_t)T::from_f32(g1) << 16);
@@ -435,6 +501,158 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
       if (ok_v) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pv[0], pv[1], pv[2], pv[3]};
       if (ok_g) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol + gap) = u32x4{pg[0], pg[1], pg[2], pg[3]};
     }
+  }
+}
+
+// ---- persistent GEGLU (round 5) -----------------------------------------------------------------------------------------------------
+// The same main loop as k_gemm_8phase<T, 0, false>, one workgroup per CU walking the tile ids b, b + G, b + 2G, ... (G a multiple of 8:
+// a workgroup stays on its XCD and an XCD's workgroups walk its 8 x 4 tile groups together).  The NEXT tile's bias loads and 14
+// prologue LDS-DMAs are issued right after the barrier pair that ends the current tile, BEFORE its epilogue -- both LDS buffers are
+// free there (every fragment read precedes the MFMAs that precede the barrier) and the GELU epilogue (~2.5 us) touches registers and
+// global memory only, so the next fill runs under it.  Same arithmetic in the same order: bit-identical to the one-tile-per-workgroup
+// kernel (round 4, tools/gemm_persist: +2.5 ... 5.6 % on the UNet's GEGLU shapes).  LDS hazards of the overlap replayed in
+// tools/emulate_gemm_kernel.py --persist.
+struct TilePos {
+  int m0, n0;
+};
+__device__ __forceinline__ TilePos geglu_tile_of(int bid, int n_blocks, int n_blocks_n) {
+  const int q = n_blocks >> 3, r = n_blocks & 7, xcd = bid & 7;
+  const int tid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int n_blocks_m = n_blocks / n_blocks_n;
+  const int per_group = 8 * n_blocks_n, grp = tid / per_group, first = grp * 8;
+  const int rows_here = n_blocks_m - first < 8 ? n_blocks_m - first : 8;
+  return TilePos{(first + (tid % per_group) % rows_here) * BM, ((tid % per_group) / rows_here) * BN};
+}
+
+template <class T>
+__global__ void __launch_bounds__(512, 2)
+k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
+                uint16_t* __restrict__ out, int M, int K, int I, int n_blocks_n, int n_blocks) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wrow = wave >> 2, wcol = wave & 3;
+  const int ps = swz(16 * lane), srow = ps >> 6, skb = ps & 63;
+  const int row_bytes = K * 2;
+  const int rd = swz((lane & 15) * 64 + (lane >> 4) * 16);
+  const int nt = K / BK;
+  const bool early = nt >= 3;
+
+  auto setup = [&](TilePos tp) {
+    Ctx c;
+    c.wave = wave;
+    c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * row_bytes), 0x00020000);
+    c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)2 * I * row_bytes), 0x00020000);
+    c.x_voff[0] = (tp.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow) * row_bytes + skb;
+    c.x_voff[1] = c.x_voff[0] + 64 * row_bytes;
+    c.img_w = 0, c.cin2 = row_bytes, c.cpt = 1;
+    c.px_mask[0] = c.px_mask[1] = 0;
+    c.w_voff[0] = (tp.n0 + 32 * (wave >> 1) + 8 * (srow >> 2) + (srow & 3) + 4 * (wave & 1)) * row_bytes + skb;
+    c.w_voff[1] = c.w_voff[0] + I * row_bytes;
+    c.xrd = rd + wrow * 8 * (2 * SUB);
+    c.wrd = rd + W_REGION + wcol * 2 * (2 * SUB);
+    return c;
+  };
+  auto load_bias = [&](int ncol, u32x4& bv_raw, u32x4& bg_raw) {
+    bv_raw = u32x4{0, 0, 0, 0}, bg_raw = u32x4{0, 0, 0, 0};
+    if (bias) {
+      bv_raw = *reinterpret_cast<const u32x4*>(bias + ncol);
+      bg_raw = *reinterpret_cast<const u32x4*>(bias + I + ncol);
+    }
+  };
+  auto issue_prologue = [&](const Ctx& c) {   // all of K tile 0, then the three half tiles of K tile 1 the loop does not stage itself
+    const KPos p0 = {0, 0, 0}, p1 = {1, 0, 0};
+    stage_w<0>(lds, c, 0, 0);
+    stage_x<0, false>(lds, c, p0, 0);
+    stage_w<0>(lds, c, 0, 1);
+    stage_x<0, false>(lds, c, p0, 1);
+    if (nt > 1) {
+      stage_w<1>(lds, c, 1, 0);
+      stage_x<1, false>(lds, c, p1, 0);
+      stage_w<1>(lds, c, 1, 1);
+    }
+  };
+
+  int bid = blockIdx.x;
+  TilePos tp = geglu_tile_of(bid, n_blocks, n_blocks_n);
+  Ctx c = setup(tp);
+  u32x4 bias_v, bias_g;
+  load_bias(tp.n0 + 32 * wcol + 8 * (lane >> 4), bias_v, bias_g);
+  issue_prologue(c);
+
+  for (;;) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frags<T> f;
+    KPos pa = {1, 0, 0}, pb = {2, 0, 0};
+    if (nt > 1) {
+      if (early) ED_WAIT_VM(10);
+      else ED_WAIT_VM(6);
+    } else {
+      ED_WAIT_VM(0);
+    }
+    ED_BARRIER();
+    if (wrow == 1) ED_BARRIER();
+
+    int t = 0;
+    if (early) {
+      tile_phases<T, 0, false, true>(lds, c, f, acc, 0, true, true, pa, pb);
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      tile_phases<T, 1, false>(lds, c, f, acc, 1, true, 3 < nt, pa, pb);
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      t = 2;
+    }
+    for (; t + 1 < nt; t += 2) {
+      tile_phases<T, 0, false>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      tile_phases<T, 1, false>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt, pa, pb);
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+    }
+    if (t < nt) tile_phases<T, 0, false>(lds, c, f, acc, t, false, false, pa, pb);
+    if (wrow == 0) ED_BARRIER();
+
+    // the VM queue is empty here (the last K tiles end with vmcnt(0)): converting the bias costs no wait
+    const int m0 = tp.m0, ncol = tp.n0 + 32 * wcol + 8 * (lane >> 4);
+    float bv[2][4], bg[2][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bv[e >> 2][e & 3] = T::to_f32((uint16_t)(bias_v[e >> 1] >> (16 * (e & 1))));
+      bg[e >> 2][e & 3] = T::to_f32((uint16_t)(bias_g[e >> 1] >> (16 * (e & 1))));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bv[e >> 2][e & 3]), "+v"(bg[e >> 2][e & 3]));
+
+    const int next = bid + (int)gridDim.x;
+    const bool has_next = next < n_blocks;     // wave-uniform
+    Ctx c2 = c;
+    TilePos tp2 = tp;
+    if (has_next) {     // next tile: addresses, its bias loads (the oldest entries of the queue), then its prologue DMAs
+      tp2 = geglu_tile_of(next, n_blocks, n_blocks_n);
+      c2 = setup(tp2);
+      load_bias(tp2.n0 + 32 * wcol + 8 * (lane >> 4), bias_v, bias_g);
+      __builtin_amdgcn_sched_barrier(0);     // the two loads stay AHEAD of the DMAs (left alone, hipcc sinks them below the epilogue)
+      issue_prologue(c2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
+      uint32_t pk[4];
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          float o0 = (acc[mb][nf][2 * jj] + bv[nf][2 * jj]) * gelu_as(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
+          float o1 = (acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) * gelu_as(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
+          pk[nf * 2 + jj] = (uint32_t)T::from_f32(o0) | ((uint32_t)T::from_f32(o1) << 16);
+        }
+      if (m < M) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+    }
+    if (!has_next) break;
+    bid = next, tp = tp2, c = c2;
   }
 }
 
@@ -455,14 +673,17 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   const int64_t nb = ((M + BM - 1) / BM) * nbn;
   if (nb >= (1ll << 31) || M >= (1ll << 31)) return bad;
   hipStream_t s = (hipStream_t)stream;
-#define ED_LAUNCH(TT)                                                                                                          \
-  k_gemm_8phase<TT, EPI, CONV><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,          \
-                                                       (const uint16_t*)row_bias, (const uint16_t*)residual, (uint16_t*)out,  \
-                                                       (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1)
+  const bool add = EPI == 1 && (row_bias || residual);
+#define ED_LAUNCH(TT, ADD_)                                                                                                          \
+  k_gemm_8phase<TT, EPI, CONV, ADD_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,          \
+                                                             (const uint16_t*)row_bias, (const uint16_t*)residual, (uint16_t*)out,  \
+                                                             (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1)
   if (dtype == ED_BF16) {
-    ED_LAUNCH(BF);
+    if (EPI == 0 || add) ED_LAUNCH(BF, true);
+    else ED_LAUNCH(BF, EPI == 0);      // (false for the plain projection / convolution; no second GEGLU instantiation)
   } else if (dtype == ED_F16) {
-    ED_LAUNCH(HF);
+    if (EPI == 0 || add) ED_LAUNCH(HF, true);
+    else ED_LAUNCH(HF, EPI == 0);
   } else {
     return bad;
   }
@@ -473,7 +694,32 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
 extern "C" {
 
 int ed_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int dtype, int64_t M, int K, int I, void* stream) {
-  return launch<0, false>(x, w, bias, nullptr, nullptr, out, dtype, M, K, I, 0, 0, 0, stream);
+  if (M == 0) return 0;
+  const int bad = (int)hipErrorInvalidValue;
+  if (M < 0 || K % BK != 0 || K < BK || I <= 0 || I % BN != 0) return bad;
+  if (M * (int64_t)K * 2 >= 0x7ffffff0ll || (int64_t)2 * I * K * 2 >= 0x7ffffff0ll) return bad;   // 32-bit buffer offsets
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15u)) return bad;
+  const int nbn = I / BN;
+  const int64_t nb = ((M + BM - 1) / BM) * nbn;
+  if (nb >= (1ll << 31) || M >= (1ll << 31)) return bad;
+  // one workgroup per CU (128 KiB of LDS each); a multiple of 8 keeps a workgroup on its XCD for all of its tiles
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return (int)hipErrorInvalidDevice;
+    cus[dev] = n / 8 * 8;
+  }
+  const int grid = nb < cus[dev] ? (int)nb : cus[dev];
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == ED_BF16)
+    k_geglu_persist<BF><<<grid, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M, K, I, nbn, (int)nb);
+  else if (dtype == ED_F16)
+    k_geglu_persist<HF><<<grid, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M, K, I, nbn, (int)nb);
+  else
+    return bad;
+  return (int)hipGetLastError();
 }
 
 int ed_linear(const void* x, const void* w, const void* bias, const void* residual, void* out, int dtype, int64_t M, int K, int N,

@@ -1,6 +1,8 @@
-"""GPU probe: the patched library (tools/r5_patches/build/libelastic_hip_patched.so) against the product's, entry point by entry point --
-results must be bit-identical (the patches move instructions, they do not change arithmetic); interleaved timing, median.
-    python tools/r5_patches/probe_patched.py [--rounds 5]"""
+"""GPU probe: one build of the library against another, entry point by entry point -- results must be bit-identical (the round-5
+patches move instructions, they do not change arithmetic); interleaved timing, median.  Since the patches landed in the product
+(round 5) the default pair is: base = the round-4 product library kept as tools/r5_patches/build/libelastic_hip_r4_product.so,
+new = the product's libelastic_hip.so.  A case either library rejects is reported with its return codes and skipped.
+    python tools/r5_patches/probe_patched.py [--rounds 5] [--base FILE] [--lib FILE]"""
 import argparse
 import ctypes
 import json
@@ -15,13 +17,22 @@ from elasticdiffusion_official_amd import _hip
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
-ap.add_argument("--lib", default="libelastic_hip_patched.so", help="file under tools/r5_patches/build/ (build_patched.py --only ... --out ...)")
+ap.add_argument("--base", default="libelastic_hip_r4_product.so", help="file under tools/r5_patches/build/, or 'product'")
+ap.add_argument("--lib", default="product", help="file under tools/r5_patches/build/ (build_patched.py --only ... --out ...), or 'product'")
 a = ap.parse_args()
-prod = _hip.lib()
-pat = ctypes.CDLL(os.path.join(HERE, "build", a.lib))
-for name in ("ed_linear", "ed_geglu_gemm", "ed_conv3x3_nhwc", "ed_flash_attention"):
-    getattr(pat, name).argtypes = _hip.SIGNATURES[name]
-    getattr(pat, name).restype = ctypes.c_int
+
+
+def load(name):
+    if name == "product":
+        return _hip.lib()
+    L = ctypes.CDLL(os.path.join(HERE, "build", name))
+    for fn in ("ed_linear", "ed_geglu_gemm", "ed_conv3x3_nhwc", "ed_flash_attention"):
+        getattr(L, fn).argtypes = _hip.SIGNATURES[fn]
+        getattr(L, fn).restype = ctypes.c_int
+    return L
+
+
+prod, pat = load(a.base), load(a.lib)
 st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
 g = torch.Generator(device="cuda").manual_seed(0)
 
@@ -43,7 +54,10 @@ def compare(name, call, outs, flops, rounds=a.rounds):
     same = True
     for _ in range(3):
         outs[0].zero_(), outs[1].zero_()
-        assert call(prod, outs[0]) == 0 and call(pat, outs[1]) == 0
+        rc = (call(prod, outs[0]), call(pat, outs[1]))
+        if rc != (0, 0):
+            print(json.dumps({"case": name, "skipped": True, "rc_base": rc[0], "rc_new": rc[1]}), flush=True)
+            return
         same = same and bool(torch.equal(outs[0], outs[1]))
     tp, tq = [], []
     for _ in range(rounds):
