@@ -260,6 +260,11 @@ def main():
                          "control flow can be exercised in seconds; the metric name says so and the number means nothing")
     ap.add_argument("--cache-backgrounds", action="store_true",
                     help="reuse the noised pad-background frames across images of the same size (off: every image pays)")
+    ap.add_argument("--fp32-leg", default="auto", choices=["auto", "on", "off"],
+                    help="after the timed region: ONE image of the same workload and seed with the fp32 UNet (the only precision "
+                         "that meets BASELINE.json's 1e-3), timed, and the rel-L2 of the benchmarked 16-bit latent against it -- "
+                         "`tolerance.fp32_unet_same_workload`, ~100 s.  auto: on for the headline workload at N = 1 with at least "
+                         "2 timed images (the driver's command), off otherwise")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: initialise RCCL with one rank and send every sharded batch through the all-gather path "
                          "(what a 1-GPU box can exercise of the multi-GPU exchange)")
@@ -326,9 +331,9 @@ def main():
         inject["unet"], inject["vae"], inject["controlnet"] = models.build_models(wl["sd"], device=dev, dtype=dtype,
                                                                                   small=True, controlnet=True)
 
-    def make_pipe(group, **inj):
+    def make_pipe(group, model_dtype=None, **inj):
         """the workload's pipeline class over process group ``group`` (False = unsharded)"""
-        common = dict(view_batch_size=wl["vbs"], model_dtype=dtype, process_group=group,
+        common = dict(view_batch_size=wl["vbs"], model_dtype=model_dtype or dtype, process_group=group,
                       cache_backgrounds=args.cache_backgrounds, **inj)
         if cn_scale is not None:
             from elasticdiffusion_official_amd import ElasticDiffusionControlNet
@@ -411,6 +416,8 @@ def main():
     elapsed = timed(pipe, 0, n_timed, m, n_groups, group_id)
     ktimes = ops.TIMER.stop() if timing else {}
     lat_timed = state["latency"]
+    # the last timed image's latent (seed n_timed - 1), for the live comparison with the fp32 UNet after the timed region
+    z16_last = pipe.last_latents.detach().clone() if (world == 1 and m == 1 and pipe.last_latents is not None) else None
     finite = bool(torch.isfinite(state["imgs"]).all()) if state["imgs"] is not None else True
     phases = pipe.phase_times()
     host_ms = {k: round(1e3 * v, 1) for k, v in pipe.host_s.items()}
@@ -446,6 +453,16 @@ def main():
                                          images_per_s=round(cnt / timed(p2, 4100, cnt, mm, ng, gid), 5))
         except Exception as e:  # noqa: BLE001
             extras_error = f"{type(e).__name__}: {e}"[:300]
+
+    # ---- north_star's tolerance, measured live: the same workload, same seed, fp32 UNet -----------------
+    fp32_live = None
+    want_fp32 = args.fp32_leg == "on" or (args.fp32_leg == "auto" and args.workload == "sdxl_1024x2048" and args.timesteps == 50
+                                          and n_timed >= 2 and not args.no_extras)
+    if want_fp32 and world == 1 and m == 1 and dtype != torch.float32 and not args.small and z16_last is not None:
+        try:
+            fp32_live = fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, n_timed - 1, z16_last, args.dtype)
+        except Exception as e:  # noqa: BLE001 -- never costs the run its headline line
+            fp32_live = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         fam = models.family(wl["sd"])
@@ -538,7 +555,7 @@ def main():
             "latency_note": (f"{m} image(s) in flight per shard group: the value above is THROUGHPUT (images completed per "
                              "second); one image takes latency_s_per_image from its first kernel to its decoded pixels"),
             "rccl": rccl,
-            "tolerance": tolerance_statement(args.dtype),
+            "tolerance": tolerance_statement(args.dtype, fp32_live),
             "per_view_unet_ms": round(per_view_ms, 3),
             "finite_output": finite,
             "graphs": graph_stats,
@@ -591,22 +608,58 @@ def parity_leg(dev, dtype_name="bf16"):
             f"reference_call_pattern_{dtype_name}_vs_fp32_oracle": f(rep["ref_pattern_vs_fp32_" + dtype_name]),
             f"{dtype_name}_vs_reference_call_pattern": f(rep["batching_" + dtype_name]),
             "fp32_vs_fp32_oracle": f(rep["fp32"]),
-            "gate_1p5x_reference_pattern": {"ok": bool(ok), "detail": msg},
+            "gate_vs_reference_gpu_arithmetic": {"ok": bool(ok), "detail": msg, "factor": realarch.GATE_FACTOR, "slack": realarch.GATE_SLACK,
+                                                 "comparator": rep.get("comparator")},
             "rng_end_state_equal": bool(rep[dtype_name + "_rng_tail_equal"] and rep["fp32_rng_tail_equal"]),
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def tolerance_statement(dtype_name):
+def fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, seed, z16, dtype_name):
+    """ONE image of the benchmarked workload with the fp32 UNet (same seeded weights before the 16-bit cast, same VAE object, same
+    seed as the last timed image), after a 1-timestep warm-up image that captures its hipGraphs: what north_star's 1e-3 costs on this
+    chip, on the driver's own clock, and how far the benchmarked 16-bit latent is from it at FULL width over all 50 timesteps (the
+    fp32 product loop is the reference's CPU path to 4e-6: tests/test_real_arch_parity.py, so it stands in for it here)."""
+    t_build = time.perf_counter()
+    p32 = make_pipe(False, model_dtype=torch.float32, vae=pipe.vae)
+    p32.seed_everything(12345)
+    p32.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", progress=lambda it: it,
+                       **dict(kw, num_inference_steps=1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    p32.seed_everything(seed)
+    imgs, _ = p32.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", progress=lambda it: it, **kw)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    z32 = p32.last_latents.double()
+    rel = float((z16.double() - z32).norm() / z32.norm())
+    out = {"images_per_s": round(1.0 / el, 5), "s_per_image": round(el, 2), "images": 1, "seed": seed,
+           "unet": "fp32 weights and activations, plain torch ops (hipBLASLt / MIOpen fp32), hipGraph replay",
+           "meets": "1e-3 rel-L2 vs the reference CPU path (fp32_model_vs_reference_cpu_path above; the fp32 loop is gated at 1e-3 "
+                    "against the oracle in tests/test_real_arch_parity.py)",
+           f"{dtype_name}_latent_vs_fp32_latent_rel_l2_full_width_{kw['num_inference_steps']}_steps": float(f"{rel:.4e}"),
+           "finite": bool(torch.isfinite(imgs).all()), "graphs": p32._runner.stats(),
+           "source": "measured live by this run, after the timed region", "leg_seconds": round(time.perf_counter() - t_build, 1)}
+    del p32
+    torch.cuda.empty_cache()
+    return out
+
+
+def tolerance_statement(dtype_name, fp32_live=None):
     """What the benchmarked dtype meets, with the committed evidence (profiles/r3_precision.json, tools/r3_precision.py):
     BASELINE.json's 1e-3 rel-L2 is a statement about the fp32 model; a 16-bit UNet -- the reference's own GPU path runs it
-    under fp16 autocast (ED:1012) -- is held to 1.5x the drift of the reference's call pattern with the same 16-bit model."""
+    under fp16 autocast (ED:1012) -- is held to 1.25x the drift of the reference's call pattern in the reference's own GPU arithmetic (fp32 weights under
+    torch.autocast: tests/realarch.AutocastOnDevice)."""
     doc = load_profile_json("r3_precision.json") or {}
     loop = doc.get("loop", {}).get("cfg3_xl_1024x2048", {})
     fw = doc.get("full_width", {}).get("batches", {})
     st = {"fp32_model_vs_reference_cpu_path": {"bar": 1e-3, "measured_max": max(loop["fp32"]) if loop.get("fp32") else None},
           "benchmarked_dtype": dtype_name,
-          "bar_16bit": "per-timestep rel-L2 vs the fp32 oracle <= 1.5 x that of the reference's call pattern driving the same "
-                       "16-bit model (tests/realarch.gate_16bit; tests/test_real_arch_parity.py)",
+          "bar_16bit": "per-timestep rel-L2 vs the fp32 oracle <= 1.25 x (+ 2e-4) that of the reference's call pattern in the reference's "
+                       "own GPU arithmetic, fp32 weights under torch.autocast (tests/realarch.gate_16bit; tests/test_real_arch_parity.py)",
+          "why_no_16bit_unet_meets_1e-3": "profiles/r5_precision_attribution.json: of the 1.3e-3 one fp16 forward errs by at full width, "
+                                          "9.2e-4 is the rounding of the MFMA operands (weights 6.7e-4, activations 6.4e-4) that "
+                                          "torch.autocast imposes on the reference's own GPU path too; an fp32 residual stream "
+                                          "would remove at most 30 %",
           "evidence": "profiles/r3_precision.json"}
     if loop.get(dtype_name):
         st["measured_16bit_vs_fp32_oracle_max"] = max(loop[dtype_name])
@@ -615,6 +668,9 @@ def tolerance_statement(dtype_name):
         st["full_width_forward_rel_l2_vs_fp32"] = {b: v.get(dtype_name) for b, v in fw.items()}
     # what BASELINE.json's own tolerance costs on this chip: the same workload with the fp32 UNet (plain torch ops, no 16-bit
     # kernels), measured once per round with `bench.py --dtype fp32 --steps 1` and committed
+    if fp32_live is not None:
+        st["fp32_unet_same_workload"] = fp32_live
+        return st
     f32 = load_profile_json("bench_r4_fp32_1gpu.json")
     if f32 and f32.get("dtype") == "fp32":
         st["fp32_unet_same_workload"] = {"images_per_s": f32.get("value"), "s_per_image": round(f32.get("ms_per_step", 0) / 1e3, 2),

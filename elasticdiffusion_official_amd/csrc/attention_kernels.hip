@@ -1157,6 +1157,9 @@ int ed_flash_attention(const void* q, const void* k, const void* v, void* out, i
   hipStream_t st = (hipStream_t)stream;
   if ((v_path >= 4 && v_path <= 10)) {  // 4 / 5 / 6 = software-pipelined (5: lazy maximum, 6: + exponent-domain q), 8 = small-KV
     if (v_path == 8 && Nk > 96) return (int)hipErrorInvalidValue;
+    // the 8-wave variants' staging spans 64 key rows per pass, and 6 / 7 were only ever validated on full tiles: fewer than one
+    // 64-key tile is rejected here, not only in the Python wrapper (which asks for >= 128)
+    if ((v_path == 6 || v_path == 7 || v_path == 9 || v_path == 10) && Nk < 64) return (int)hipErrorInvalidValue;
     // the pipelined kernel addresses K / V with 32-bit byte offsets from the head's base pointer
     if (v_path != 8 && ((int64_t)(Nk + 2 * KT) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= 0x7fffffffll)) return (int)hipErrorInvalidValue;
     const int rows_per_wg = v_path == 8 ? QB * SK_QBLOCKS : (v_path >= 9 ? 2 * QB : QB);

@@ -54,10 +54,10 @@ class GraphedForward:
         self.epoch += 1
 
     @staticmethod
-    def _key(shape, dtype, cond, t_shape=()):
-        """One graph per (rows shape, dtype, condition rows, timestep shape): the timestep is a 0-d tensor when all
-        rows share it and a per-row vector when the rows of several images in flight were fused into one batch."""
-        return (tuple(shape), dtype, None if cond is None else (tuple(cond.shape), cond.dtype), tuple(t_shape))
+    def _key(shape, dtype, cond, t_shape=(), fresh_side=False):
+        """One graph per (rows shape, dtype, condition rows, timestep shape, fresh side inputs): the timestep is a 0-d tensor
+        when all rows share it and a per-row vector when the rows of several images in flight were fused into one batch."""
+        return (tuple(shape), dtype, None if cond is None else (tuple(cond.shape), cond.dtype), tuple(t_shape), bool(fresh_side))
 
     def input_rows(self, shape, dtype, device, cond=None):
         """The static model-input tensor for this batch shape (allocated on first request; 0-d timestep)."""
@@ -70,13 +70,15 @@ class GraphedForward:
             self.entries[key] = ent
         return ent["x"]
 
-    def _capture(self, ent, t, text, pooled, cond):
+    def _capture(self, ent, t, text, pooled, cond, fresh_side=False):
         x = ent["x"]
         ent["t"] = t.clone()
         ent["text"] = None if text is None else text.clone()
         ent["pooled"] = None if pooled is None else pooled.clone()
         ent["cond"] = None if cond is None else cond.clone()
-        ent["extra"] = self.prepare(ent["text"])
+        # side inputs that change on every call (fused batches of several images in flight) leave nothing to hoist: their
+        # k / v projections stay INSIDE the graph (extra = None) instead of ~70 eager launches in front of every replay
+        ent["extra"] = None if fresh_side else self.prepare(ent["text"])
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -105,7 +107,7 @@ class GraphedForward:
         in flight), so they are copied into the graph's static buffers on every replay, not once per image."""
         if not self.enabled:
             return self.fwd(x, t, text, pooled, cond, None)
-        key = self._key(x.shape, x.dtype, cond, t.shape)
+        key = self._key(x.shape, x.dtype, cond, t.shape, fresh_side)
         ent = self.entries.get(key)
         if ent is None:
             ent = {"x": torch.empty_like(x), "graph": None, "epoch": -1, "eager": False}
@@ -116,7 +118,7 @@ class GraphedForward:
             ent["x"].copy_(x)
         if ent["graph"] is None:
             try:
-                self._capture(ent, t, text, pooled, cond)
+                self._capture(ent, t, text, pooled, cond, fresh_side)
             except Exception as e:  # noqa: BLE001 -- a library that cannot be captured must not take the path down
                 warnings.warn(f"hipGraph capture failed for rows {tuple(x.shape)} ({type(e).__name__}: {e}); "
                               "running this shape eagerly")

@@ -131,9 +131,10 @@ def linear_(x, weight, bias=None):
     return F.linear(x, weight, bias)
 
 
-def _hip_conv3x3(x, conv):
-    """Can ``conv`` (3x3, stride 1, padding 1) on the channels-last 16-bit activation ``x`` run as ed_conv3x3_nhwc?"""
-    if not (HIP_CONV3X3 and _fusable_nhwc(x)):
+def _hip_conv3x3(x, conv, shape_only=False):
+    """Can ``conv`` (3x3, stride 1, padding 1) on the channels-last 16-bit activation ``x`` run as ed_conv3x3_nhwc?
+    ``shape_only``: ``x`` only stands for the shape / dtype of an activation that does not exist yet."""
+    if not (HIP_CONV3X3 and (shape_only or _fusable_nhwc(x))):
         return False
     w = conv.weight
     if w.dtype != x.dtype or not w.is_contiguous(memory_format=torch.channels_last):
@@ -210,7 +211,10 @@ class ResnetBlock2D(nn.Module):
         sc = self.conv_shortcut
         cout = self.conv1.out_channels
         cl = _fusable_nhwc(x) and cout % 8 == 0 and cout // self.norm2.num_groups >= 8
-        if cl and _hip_conv3x3(x, self.conv1) and self.conv2.weight.is_contiguous(memory_format=torch.channels_last):
+        # both norms must take the channels-last HIP kernel (its torch fallback hands back an NCHW tensor the convolution
+        # wrapper rejects) and BOTH convolutions must be shapes the kernel takes: conv2's Cin is cout
+        if (cl and x.shape[1] // self.norm1.num_groups >= 8 and _hip_conv3x3(x, self.conv1)
+                and _hip_conv3x3(x[:, :1].expand(-1, cout, -1, -1), self.conv2, shape_only=True)):
             # both convolutions as ed_conv3x3_nhwc: conv1's epilogue adds its bias and the time embedding, conv2's its bias and
             # the block's residual -- the two broadcast adds and the closing add never exist as separate passes
             from . import ops
@@ -279,8 +283,8 @@ class Attention(nn.Module):
         the latent, not on the timestep -- so a caller may compute them once per image and hand them to ``forward`` (``kv``)
         instead of re-projecting the same 77 tokens in every one of the ~100 forwards of an image (UNet.cross_attention_kv)."""
         w = self._fused_weight(("to_k", "to_v"))
-        if out is None:
-            return F.linear(context, w)
+        if out is None:   # the same library call for the first projection and every refresh: one hipBLASLt solution, same bits
+            out = torch.empty(context.shape[:-1] + (w.shape[0],), dtype=context.dtype, device=context.device)
         torch.matmul(context, w.t(), out=out)
         return out
 
@@ -330,7 +334,7 @@ class GEGLU(nn.Module):
     def forward(self, x):
         if HIP_GEGLU_GEMM and FUSED_KERNELS and _fusable(x) and self.proj.weight.dtype == x.dtype:
             from . import ops
-            if ops.geglu_gemm_ok(x.numel() // x.shape[-1], x.shape[-1], self.proj.out_features // 2):
+            if ops.geglu_gemm_wins(x.numel() // x.shape[-1], x.shape[-1], self.proj.out_features // 2):
                 return ops.geglu_gemm(x, self.proj.weight, self.proj.bias)
         y = self.proj(x)
         if _fusable(y) and (y.shape[-1] // 2) % 8 == 0:

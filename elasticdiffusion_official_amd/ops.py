@@ -359,6 +359,14 @@ def geglu_gemm_ok(M, K, I):
     return K % 64 == 0 and K >= 64 and I % GEMM_BN == 0 and M * K * 2 < 2 ** 31 - 16 and 2 * I * K * 2 < 2 ** 31 - 16
 
 
+def geglu_gemm_wins(M, K, I):
+    """Where the model uses ed_geglu_gemm: every shape the kernel takes whose grid fills the chip.  The fused pair beats hipBLASLt +
+    ed_geglu by 1.11-1.91 x on full grids, but it is the same main loop as ed_linear, which loses 2.4 x on a 25-tile grid
+    (one 128-KiB-LDS workgroup per CU): a batch-1 / batch-2 forward at the 16 x 16 or 32 x 32 level stays with the library
+    (ADVICE r4).  The GEGLU kernel is persistent (one workgroup per CU walking the tiles), so there is no round-fill condition."""
+    return geglu_gemm_ok(M, K, I) and -(-M // GEMM_BM) * (I // GEMM_BN) >= GEMM_MIN_BLOCKS
+
+
 def geglu_gemm(x, w, bias=None):
     """x [..., K], w [2I, K], bias [2I] -> [..., I] = (x w_v^T + b_v) * gelu(x w_g^T + b_g).  See ed_geglu_gemm."""
     M, K = _gemm_x(x, "x")

@@ -416,9 +416,11 @@ class ElasticDiffusion(nn.Module):
         if not self.TEXT_KV_ONCE or not hasattr(self.unet, "cross_attention_kv"):
             return None
         out = {} if into is None else into
-        out["unet"] = self.unet.cross_attention_kv(txt, None if into is None else into["unet"])
+        # a part that is missing from ``into`` (a ControlNet attached after this batch shape was captured) is allocated here;
+        # the captured graph cannot read it, but the runner's entries are dropped when the ControlNet changes (set_controlnet)
+        out["unet"] = self.unet.cross_attention_kv(txt, out.get("unet"))
         if self.controlnet is not None and hasattr(self.controlnet, "cross_attention_kv"):
-            out["controlnet"] = self.controlnet.cross_attention_kv(txt, None if into is None else into["controlnet"])
+            out["controlnet"] = self.controlnet.cross_attention_kv(txt, out.get("controlnet"))
         return out
 
     def _forward_rows(self, x, t_dev, txt, pl, cond, text_kv=None):

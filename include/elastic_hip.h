@@ -305,7 +305,9 @@ int ed_phase_epilogue(const void* g_out, const void* v_out, int dtype, const flo
  *   7 = 4 with every LDS operand read issued three MFMAs ahead of its use instead of one (a 4-deep register ring).
  *   9 / 10 = 4 / 5 with 8 waves (256 query rows) per workgroup: each K / V tile is staged once for twice the query rows.
  *   K / V tile loads of 4 .. 7, 9, 10 carry their whole byte offset in the per-lane offset: rows past Nk read as zeros by the
- *   buffer range check, which does not cover a scalar offset.
+ *   buffer range check, which does not cover a scalar offset.  6, 7, 9 and 10 return hipErrorInvalidValue for Nk < 64 (less than one
+ *   full key tile); the exponent-domain contract of 6 (q pre-multiplied, `scale` ignored) can only be honoured by the caller -- the
+ *   Python wrapper is what checks it.
  */
 int ed_flash_attention(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq, int Nk,
                        int head_dim, int64_t q_sb, int64_t q_sn, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn,

@@ -89,6 +89,29 @@ class OnDevice(nn.Module):
         return [d.float().cpu() for d in down], mid.float().cpu()
 
 
+class AutocastOnDevice(OnDevice):
+    """The arithmetic of the reference's OWN GPU path: fp32 weights (ED:121, `torch_dtype = float32` unless low_vram) inside
+    ``torch.autocast('cuda')`` (ED:1012) -- Linear / Conv2d / attention take 16-bit copies of their inputs and weights and return
+    16-bit results (so the residual sums are 16-bit too), GroupNorm / LayerNorm / softmax run in fp32 -- with plain torch ops (every
+    fused-kernel switch off, as diffusers would run it).  This is the comparator of the 16-bit gate since round 5 (VERDICT r4
+    item 1b); rounds 2-4 compared against this repo's pure-16-bit module, which is close to but not what the reference computes."""
+
+    def __init__(self, mod, device, dtype):
+        super().__init__(mod, device, torch.float32)
+        self.cast = dtype
+
+    @torch.no_grad()
+    def forward(self, x, t, **kw):
+        from elasticdiffusion_official_amd import models as M
+        saved = M.FUSED_KERNELS
+        M.FUSED_KERNELS = False
+        try:
+            with torch.autocast(torch.device(self.dev).type, dtype=self.cast):
+                return super().forward(x, t, **kw)
+        finally:
+            M.FUSED_KERNELS = saved
+
+
 def run_oracle(case, unet, vae, cn):
     """The oracle loop on the CPU -> (per-timestep latents, rng tail)."""
     c = REAL_CASES[case] if isinstance(case, str) else case
@@ -136,13 +159,15 @@ LONG_CASES = {
 }
 
 
-def drift_report(case, dtype=torch.bfloat16, device="cuda:0", with_fp32=True, with_batching=True, dtypes=None):
+def drift_report(case, dtype=torch.bfloat16, device="cuda:0", with_fp32=True, with_batching=True, dtypes=None, comparator="autocast"):
     """-> dict of per-timestep rel-L2 lists (see module docstring) + RNG-tail equality flags.
 
     ``dtypes`` (names from DTYPES, default: just ``dtype`` reported under its name; bf16 is also reported under the
     legacy keys "batching" / "ref_pattern_vs_fp32"): for every 16-bit dtype d
         out[d]                            product (fused kernels, K-batched, hipGraph) in d      vs fp32 oracle
-        out["ref_pattern_vs_fp32_" + d]   the reference's call pattern driving the same d model  vs fp32 oracle
+        out["ref_pattern_vs_fp32_" + d]   the reference's call pattern AND GPU arithmetic (fp32 weights under torch.autocast(d),
+                                          plain torch ops: AutocastOnDevice; ``comparator="pure16"``: the round 2-4 comparator,
+                                          this repo's module with d weights)                      vs fp32 oracle
         out["batching_" + d]              product in d vs that reference-pattern run
     fp16 is the dtype the reference's own GPU path runs the UNet in (CUDA autocast, ED:1012)."""
     c = REAL_CASES[case] if isinstance(case, str) else case
@@ -163,7 +188,9 @@ def drift_report(case, dtype=torch.bfloat16, device="cuda:0", with_fp32=True, wi
         out[name + "_finite"] = bool(all(torch.isfinite(z).all() for z in got16))
         out["graphs"] = pipe._runner.stats()
         if with_batching:
-            ref_pattern, _ = run_oracle(c, OnDevice(unet, device, dt), vae, None if cn is None else OnDevice(cn, device, dt))
+            wrap = AutocastOnDevice if comparator == "autocast" else OnDevice
+            ref_pattern, _ = run_oracle(c, wrap(unet, device, dt), vae, None if cn is None else wrap(cn, device, dt))
+            out["comparator"] = comparator
             out["batching_" + name] = [rel_l2(a, b) for a, b in zip(got16, ref_pattern)]
             out["ref_pattern_vs_fp32_" + name] = [rel_l2(a, b) for a, b in zip(ref_pattern, want)]
             if name == "bf16":
@@ -171,15 +198,22 @@ def drift_report(case, dtype=torch.bfloat16, device="cuda:0", with_fp32=True, wi
     return out
 
 
+# Round 5 (VERDICT r4 "What's weak"): the comparator is the reference's own GPU arithmetic (AutocastOnDevice) and the factor is
+# 1.25 + 2e-4 instead of 1.5 + 1e-3 -- measured product / comparator ratios are 0.82-1.06 (profiles/r3_precision.json,
+# r4_parity_real_arch.json), so a model uniformly 1.4x worse than today's no longer passes.
+GATE_FACTOR, GATE_SLACK = 1.25, 2e-4
+
+
 def gate_16bit(rep, name):
-    """The bar a 16-bit loop has to meet: its drift against the fp32 oracle may not exceed 1.5x the
-    drift of the REFERENCE'S OWN call pattern (batch-2 + view batches, ED:661-681, 830-850) driving the same 16-bit
-    model -- i.e. K-batching, the fused kernels and the hipGraph add at most half again to what the dtype itself costs the
-    reference -- and the two 16-bit runs may differ from each other by no more than 2x that (independent rounding noise
-    adds in quadrature: sqrt(2) expected).  -> (ok, message)"""
+    """The bar a 16-bit loop has to meet (tightened in round 5): its drift against the fp32 oracle may not
+    exceed GATE_FACTOR x the drift of the REFERENCE'S OWN call pattern (batch-2 + view batches, ED:661-681, 830-850) in the
+    reference's own GPU arithmetic (fp32 weights under torch.autocast, ED:1012) -- i.e. K-batching, the fused kernels, the 16-bit
+    weights and the hipGraph add at most a quarter to what the dtype itself costs the reference -- and the two 16-bit runs may
+    differ from each other by no more than 2x that (independent rounding noise adds in quadrature: sqrt(2) expected).
+    -> (ok, message)"""
     ours, ref = max(rep[name]), max(rep["ref_pattern_vs_fp32_" + name])
     both = max(rep["batching_" + name])
-    ok = ours <= 1.5 * ref + 1e-3 and both <= 2.0 * ref + 1e-3 and rep[name + "_finite"]
+    ok = ours <= GATE_FACTOR * ref + GATE_SLACK and both <= 2.0 * ref + GATE_SLACK and rep[name + "_finite"]
     return ok, f"{name}: product {ours:.3e}, reference pattern {ref:.3e}, product-vs-pattern {both:.3e}"
 
 

@@ -37,7 +37,7 @@ def test_unet_flop_count_is_stable():
 
 def test_bench_and_cli_help_run_without_gpu():
     for cmd in ([sys.executable, "bench.py", "--help"], [sys.executable, "-m", "elasticdiffusion_official_amd", "--help"]):
-        out = subprocess.run(cmd, capture_output=True, text=True, cwd=bench.ROOT)
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=bench.ROOT, timeout=300)
         assert out.returncode == 0 and "--" in out.stdout, out.stderr
 
 
@@ -54,4 +54,4 @@ def test_workloads_cover_every_baseline_config_and_controlnet_flops():
 def test_tolerance_statement_shape():
     st = bench.tolerance_statement("bf16")
     assert st["fp32_model_vs_reference_cpu_path"]["bar"] == 1e-3 and st["benchmarked_dtype"] == "bf16"
-    assert "1.5 x" in st["bar_16bit"] and st["evidence"] == "profiles/r3_precision.json"
+    assert "1.25 x" in st["bar_16bit"] and st["evidence"] == "profiles/r3_precision.json"

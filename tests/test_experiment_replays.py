@@ -1,14 +1,15 @@
 """CPU: the lane-level replays that stand behind the round-5 experiments (tools/gemm_persist, tools/gemm_sched, tools/attn16) keep
 passing -- they are what let those kernels run correctly on their first GPU launch, and what the patches in tools/r5_patches cite."""
 import os
-import subprocess
 import sys
+
+from tests import procs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(script, *args):
-    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *args], capture_output=True, text=True, cwd=ROOT)
+    return procs.run([sys.executable, os.path.join(ROOT, "tools", script), *args], 600, cwd=ROOT)
 
 
 def test_persistent_gemm_prefetch_replay_and_its_broken_variant():

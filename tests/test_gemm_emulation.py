@@ -9,12 +9,13 @@ import sys
 
 import pytest
 
+from tests import procs
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_gemm_kernel_replay_is_exact_and_catches_broken_schedules():
-    run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_gemm_kernel.py"), "--quick", *a],
-                                    capture_output=True, text=True, cwd=ROOT)
+    run = lambda *a: procs.run([sys.executable, os.path.join(ROOT, "tools", "emulate_gemm_kernel.py"), "--quick", *a], 600, cwd=ROOT)
     ok = run()
     assert ok.returncode == 0 and "WRONG" not in ok.stdout, ok.stdout + ok.stderr
     for brk in ("war", "raw", "lgkm", "early"):   # early: the first K tile's counted waits one DMA pair too weak
@@ -26,7 +27,7 @@ def test_gemm_kernel_replay_is_exact_and_catches_broken_schedules():
 def test_gemm_kernels_compile_for_gfx950_without_spills(tmp_path):
     out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-c",
                           os.path.join(ROOT, "elasticdiffusion_official_amd", "csrc", "gemm_kernels.hip"), "-o", str(tmp_path / "gemm.o"),
-                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=str(tmp_path))
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rep = out.stderr
     # bf16 / f16 x (plain, 3x3 convolution) x (with, without epilogue addends) [x (8-phase, long-K loop) with patch 0006]; GEGLU runs the persistent loop

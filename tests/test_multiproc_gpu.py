@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests.procs import join_all
+
 pytestmark = pytest.mark.gpu
 
 
@@ -71,9 +73,7 @@ def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, ret)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    join_all(procs, 300, f"{world} ranks sharing the GPU ({name})")
     want = g[f"{name}/latent"]
     # the exchange (all-gather of model outputs) is exact; what may differ between a sharded and an unsharded run is
     # the model forward itself, because the per-rank batch shape changes the library's kernel choice (rounding order)
@@ -183,8 +183,7 @@ def test_rccl_world_size_one_exchange_path():
     ret = ctx.Manager().dict()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
     p.start()
-    p.join(600)
-    assert p.exitcode == 0
+    join_all([p], 600, "RCCL world-size-1 worker")
     assert ret["backend"] == "nccl" and ret["ranks_seen"] == 1
     outs = ret["outs"]
     for kind in ("fake_fp32", "real_fp16"):

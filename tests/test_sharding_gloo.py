@@ -10,6 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from elasticdiffusion_official_amd.sharding import RowSharder, row_partition
+from tests.procs import join_all
 
 
 def _free_port():
@@ -70,9 +71,7 @@ def test_row_sharder_matches_single_process(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, [20, 6, 1, 7, 24], ret)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    join_all(procs, 120, "row sharder over gloo")
     assert all(ret.get(r) is True for r in range(world)), dict(ret)
 
 
@@ -117,9 +116,7 @@ def test_sub_groups_shard_independently():
     procs = [ctx.Process(target=_group_worker, args=(r, world, port, g, ret)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    join_all(procs, 120, "row sharder over gloo")
     assert all(ret.get(r) is True for r in range(world)), dict(ret)
 
 
@@ -154,9 +151,7 @@ def test_row_shape_disagreement_is_an_error_not_a_hang():
     procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    join_all(procs, 120, "shape-mismatch detection over gloo")
     assert ret[0] == "raised" and ret[1] == "raised", dict(ret)
     assert ret[10] and ret[11]
 
@@ -178,5 +173,5 @@ def test_force_exchange_runs_the_collective_on_one_rank():
     ret = ctx.Manager().dict()
     p = ctx.Process(target=_forced_worker, args=(_free_port(), ret))
     p.start()
-    p.join(120)
-    assert p.exitcode == 0 and ret["ok"]
+    join_all([p], 120, "forced exchange on one rank")
+    assert ret["ok"]

@@ -34,7 +34,7 @@ import json
 d = json.loads([l for l in open("gpurun_out/r5s1/bench.json") if l.startswith("{")][-1])
 r = d.get("roofline") or {}
 print("bench", d["value"], d["ms_per_step"], d["phase_ms_last_image"], d["roofline_e2e"]["frac"], r.get("kernel"), r.get("frac"), r.get("us_per_launch"))
-print(d.get("parity_16bit_rel_l2", {}).get("gate_1p5x_reference_pattern"), d["extras"], d["graphs"])
+print(d.get("parity_16bit_rel_l2", {}).get("gate_vs_reference_gpu_arithmetic"), d["extras"], d["graphs"])
 print({k: (v.get("tflops") or v.get("gbps"), v.get("s_per_image")) for k, v in d.get("unet_kernels", {}).items()} if isinstance(d.get("unet_kernels"), dict) else d.get("unet_kernels"))
 PY
 tail -2 $O/bench.err
