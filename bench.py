@@ -616,14 +616,14 @@ def parity_leg(dev, dtype_name="bf16"):
 
 def fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, seed, z16, dtype_name):
     """ONE image of the benchmarked workload with the fp32 UNet (same seeded weights before the 16-bit cast, same VAE object, same
-    seed as the last timed image), after a 1-timestep warm-up image that captures its hipGraphs: what north_star's 1e-3 costs on this
+    seed as the last timed image), after a 2-timestep warm-up image that captures its hipGraphs and pays MIOpen's first-use searches: what north_star's 1e-3 costs on this
     chip, on the driver's own clock, and how far the benchmarked 16-bit latent is from it at FULL width over all 50 timesteps (the
     fp32 product loop is the reference's CPU path to 4e-6: tests/test_real_arch_parity.py, so it stands in for it here)."""
     t_build = time.perf_counter()
     p32 = make_pipe(False, model_dtype=torch.float32, vae=pipe.vae)
     p32.seed_everything(12345)
     p32.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", progress=lambda it: it,
-                       **dict(kw, num_inference_steps=1))
+                       **dict(kw, num_inference_steps=2))     # (2 timesteps: both phase batches, 20 and 6 rows, are captured and warm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     p32.seed_everything(seed)

@@ -13,11 +13,11 @@ import torch  # noqa: F401  (must be imported before the .so so libamdhip64 is a
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT_DIR = os.path.dirname(PKG_DIR)
-SOURCES = [os.path.join(PKG_DIR, "csrc", n) for n in ("elastic_kernels.hip", "unet_kernels.hip", "attention_kernels.hip", "gemm_kernels.hip")]
+SOURCES = [os.path.join(PKG_DIR, "csrc", n) for n in ("elastic_kernels.hip", "unet_kernels.hip", "attention_kernels.hip", "gemm_kernels.hip", "vae_kernels.hip")]
 SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT_DIR, "include")
 SO_PATH = os.path.join(PKG_DIR, "libelastic_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -60,6 +60,9 @@ SIGNATURES = {
     "ed_geglu_gemm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "ed_linear": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "ed_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_groupnorm_nhwc_f32_workspace": [_i, _i, _i, _i],
+    "ed_groupnorm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "ed_conv3x3_nhwc_f32out": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
 }
 
 _LIB = None

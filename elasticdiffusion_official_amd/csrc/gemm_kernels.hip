@@ -252,6 +252,46 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   ED_BARRIER();
 }
 
+// LONG K (round 5; the convolutions: K = 9 Cin >= 2880): the same K tile in 4 barrier intervals of 32 MFMAs instead of 8 of 16 -- half the
+// barriers and pipe drains per K tile.  Measured on the MI355X against the 8-phase loop, bit-identical (profiles/r5_s2_long_k_patch_0006_*):
+// convolutions +4 ... 12 % (32 x 32 1280 -> 1280: 1205 -> 1354 TFLOP/s), plain projections K = 1280 / 2560 -0.5 ... -2.7 %, K = 640 -1 ... -3.5 %
+// (profiles/r4_s15_*) -- hence a separate instantiation (TWO) that the launcher picks for CONVOLUTIONS of at least TWO_MIN_TILES K tiles
+// only.  No early start (the prologue waits for all of K tile 0).
+//   R1  W value + gate rows and x m-half 0 (16 fragment reads); x m-half 1 of tile + 1 -> the other buffer
+//   M1  32 MFMAs (m half 0 x value, gate)
+//   R2  x m-half 1 (8 reads); W value rows, x m-half 0, W gate rows of tile + 2 -> this buffer (all last read in R1, by either wave row one
+//       interval ago); vmcnt(6): all of tile + 1 has landed
+//   M2  32 MFMAs (m half 1 x gate, value)
+// A wave retires its fragment reads before its barrier.  Replay: tools/emulate_gemm_kernel.py --sched two_read (incl. the convolution).
+constexpr int TWO_MIN_TILES = 20;
+template <class T, int BUFI, bool CONV>
+__device__ __forceinline__ void tile_phases_two(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1, bool s2,
+                                                KPos p1, KPos p2) {
+  read_w<T, BUFI, 0>(lds, c, f);
+  read_x<T, BUFI>(lds, c, f, 0);
+  read_w<T, BUFI, 1>(lds, c, f);
+  if (s1) stage_x<BUFI ^ 1, CONV>(lds, c, p1, 1);
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 0, 0>(acc, f);
+  mma16<T, 0, 1>(acc, f);
+  ED_BARRIER();
+  read_x<T, BUFI>(lds, c, f, 1);
+  if (s2) {
+    stage_w<BUFI>(lds, c, tile + 2, 0);
+    stage_x<BUFI, CONV>(lds, c, p2, 0);
+    stage_w<BUFI>(lds, c, tile + 2, 1);
+    ED_WAIT_VM(6);
+  } else {
+    ED_WAIT_VM(0);
+  }
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 1, 1>(acc, f);
+  mma16<T, 1, 0>(acc, f);
+  ED_BARRIER();
+}
+
 // HALF tile (round 5): a column tile of the plain projection / convolution whose second 128-column half lies entirely beyond the output
 // width (N mod 256 in (0, 128]: the last tile of N = 320, 640, 1920) runs the first half only -- 256 x 128 outputs: no DMAs and no
 // fragment reads for the second half's W rows, 32 instead of 64 MFMAs per K tile and wave (those 32 multiplied zero-filled rows and
@@ -298,11 +338,15 @@ __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Fra
 //     out = round16(acc + bias[n] + row_bias[m / rows_per_sample, n] + residual[m, n])        one rounding, fp32 sums
 // ADD (EPI 1): the launch has at least one epilogue addend (row_bias / residual).  Without the flag the epilogue converted and added two
 // pairs of zero vectors per store even when both pointers were null: 1.7-3.7 % of a plain projection (profiles/r4_s15_*, r4_s17_*).
-template <class T, int EPI, bool CONV, bool ADD = true>
+// OUT32 (EPI 1, round 5: the fp32 VAE's convolutions on split 16-bit operands, vae_kernels.hip): `bias`, `residual` and `out` point to
+// fp32 data ([I], [M, I], [M, I]); out = out_scale * acc + bias + residual with NO rounding to 16 bits -- the accumulators already are
+// the fp32 result; out_scale (a power of two) undoes the pre-scaling of the split weights.  row_bias is not used.
+// TWO: the long-K loop (tile_phases_two) instead of the 8-phase one -- a separate instantiation (both loops in one kernel made hipcc spill).
+template <class T, int EPI, bool CONV, bool ADD = true, bool OUT32 = false, bool TWO = false>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
               const uint16_t* __restrict__ row_bias, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int M,
-              int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w, int rows_per_sample) {
+              int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w, int rows_per_sample, float out_scale) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
 
   // workgroup -> (row block, column block).  Id b runs on XCD b % 8: give every XCD a contiguous run of tile ids, and walk
@@ -367,7 +411,7 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   // not spend an L2 / HBM round trip waiting for 32 bytes before it may start staging (round 4; until then the values were
   // converted -- i.e. waited for -- right here).
   u32x4 bias_v = {0, 0, 0, 0}, bias_g = {0, 0, 0, 0};
-  if (bias) {
+  if (bias && !OUT32) {
     if (EPI == 0 || ncol < I) bias_v = *reinterpret_cast<const u32x4*>(bias + ncol);
     if (EPI == 0 || ncol + gap < I) bias_g = *reinterpret_cast<const u32x4*>(bias + gap + ncol);
   }
@@ -414,7 +458,8 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   stage_x<0, CONV>(lds, c, p0, 0);
   stage_w<0>(lds, c, 0, 1);
   stage_x<0, CONV>(lds, c, p0, 1);
-  const bool early = nt >= 3;     // (every real shape: K >= 320)
+  constexpr bool two = TWO;               // long K: 4 barrier intervals per K tile (tile_phases_two)
+  const bool early = nt >= 3 && !two;     // (every real shape: K >= 320)
   if (nt > 1) {
     stage_w<1>(lds, c, 1, 0);
     stage_x<1, CONV>(lds, c, pa, 0);
@@ -428,6 +473,18 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   if (wrow == 1) ED_BARRIER();    // second wave row runs half a phase behind
 
   int t = 0;
+  if (two) {
+    for (; t + 1 < nt; t += 2) {
+      tile_phases_two<T, 0, CONV>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
+      pa = pb;
+      pb = k_next<CONV>(pb, c.cpt);
+      tile_phases_two<T, 1, CONV>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt, pa, pb);
+      pa = pb;
+      pb = k_next<CONV>(pb, c.cpt);
+    }
+    if (t < nt) tile_phases_two<T, 0, CONV>(lds, c, f, acc, t, false, false, pa, pb);
+    t = nt;
+  }
   if (early) {                    // the first pair of K tiles, tile 0 in its early-start form (s1 = s2 = true: nt >= 3)
     tile_phases<T, 0, CONV, true>(lds, c, f, acc, 0, true, true, pa, pb);
     pa = pb;
@@ -449,6 +506,38 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   if (wrow == 0) ED_BARRIER();    // pair the extra barrier of the second wave row
   }   // (!half)
 
+  if (OUT32) {
+    // fp32 epilogue: a lane's 8 consecutive columns of a row are two 16-byte fp32 vectors (fragment f = columns ncol + 4 f ..)
+    const float* biasf = reinterpret_cast<const float*>(bias);
+    const float* resf = reinterpret_cast<const float*>(residual);
+    float* outf = reinterpret_cast<float*>(out);
+    const bool col_v = ncol < I, col_g = ncol + gap < I;
+    f32x4 b32[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+    if (biasf) {
+#pragma unroll
+      for (int fr = 0; fr < 2; ++fr) {
+        if (col_v) b32[0][fr] = *reinterpret_cast<const f32x4*>(biasf + ncol + 4 * fr);
+        if (col_g) b32[1][fr] = *reinterpret_cast<const f32x4*>(biasf + ncol + gap + 4 * fr);
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {      // value half / second ("gate") half of the 256 columns
+        if (!(hf == 0 ? col_v : col_g)) continue;
+        const int64_t o = (int64_t)m * I + ncol + hf * gap;
+#pragma unroll
+        for (int fr = 0; fr < 2; ++fr) {
+          f32x4 v = acc[mb][2 * hf + fr] * out_scale + b32[hf][fr];
+          if (ADD && resf) v += *reinterpret_cast<const f32x4*>(resf + o + 4 * fr);
+          *reinterpret_cast<f32x4*>(outf + o + 4 * fr) = v;
+        }
+      }
+    }
+    return;
+  }
   // epilogue: one 16-byte store per (lane, 16-row block): 8 consecutive columns of one row
   float bv[2][4], bg[2][4];
 #pragma unroll
@@ -659,9 +748,9 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
 }  // namespace
 
 // C ABI (include/elastic_hip.h).  Returns 0, a hipError_t, or hipErrorInvalidValue for a shape the kernel does not take.
-template <int EPI, bool CONV>
+template <int EPI, bool CONV, bool OUT32 = false>
 static int launch(const void* x, const void* w, const void* bias, const void* row_bias, const void* residual, void* out, int dtype,
-                  int64_t M, int K, int I, int img_h, int img_w, int rows_per_sample, void* stream) {
+                  int64_t M, int K, int I, int img_h, int img_w, int rows_per_sample, void* stream, float out_scale = 1.0f) {
   if (M == 0) return 0;
   const int bad = (int)hipErrorInvalidValue;
   if (M < 0 || K % BK != 0 || K < BK || I <= 0 || (EPI == 0 ? I % BN != 0 : I % 8 != 0)) return bad;
@@ -674,20 +763,37 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   if (nb >= (1ll << 31) || M >= (1ll << 31)) return bad;
   hipStream_t s = (hipStream_t)stream;
   const bool add = EPI == 1 && (row_bias || residual);
-#define ED_LAUNCH(TT, ADD_)                                                                                                          \
-  k_gemm_8phase<TT, EPI, CONV, ADD_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,          \
+  const bool two = CONV && K / BK >= TWO_MIN_TILES;     // the long-K loop: convolutions only (measured negative on the plain projections)
+#define ED_LAUNCH1(TT, ADD_, TWO_)                                                                                                   \
+  k_gemm_8phase<TT, EPI, CONV, ADD_, OUT32, TWO_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, \
                                                              (const uint16_t*)row_bias, (const uint16_t*)residual, (uint16_t*)out,  \
-                                                             (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1)
-  if (dtype == ED_BF16) {
-    if (EPI == 0 || add) ED_LAUNCH(BF, true);
-    else ED_LAUNCH(BF, EPI == 0);      // (false for the plain projection / convolution; no second GEGLU instantiation)
-  } else if (dtype == ED_F16) {
-    if (EPI == 0 || add) ED_LAUNCH(HF, true);
-    else ED_LAUNCH(HF, EPI == 0);
+                                                             (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1, out_scale)
+#define ED_LAUNCH(TT, ADD_)                          \
+  do {                                               \
+    if constexpr (CONV) {                            \
+      if (two) ED_LAUNCH1(TT, ADD_, true);           \
+      else ED_LAUNCH1(TT, ADD_, false);              \
+    } else {                                         \
+      ED_LAUNCH1(TT, ADD_, false);                   \
+    }                                                \
+  } while (0)
+  if constexpr (OUT32) {       // split-fp16 operands only (bf16's 8 significand bits would need three terms per operand)
+    if (dtype != ED_F16 || row_bias) return bad;
+    if (add) ED_LAUNCH(HF, true);
+    else ED_LAUNCH(HF, false);
   } else {
-    return bad;
+    if (dtype == ED_BF16) {
+      if (EPI == 0 || add) ED_LAUNCH(BF, true);
+      else ED_LAUNCH(BF, EPI == 0);      // (false for the plain projection / convolution; no second GEGLU instantiation)
+    } else if (dtype == ED_F16) {
+      if (EPI == 0 || add) ED_LAUNCH(HF, true);
+      else ED_LAUNCH(HF, EPI == 0);
+    } else {
+      return bad;
+    }
   }
 #undef ED_LAUNCH
+#undef ED_LAUNCH1
   return (int)hipGetLastError();
 }
 
@@ -731,6 +837,12 @@ int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* 
                     int dtype, int B, int H, int W, int Cin, int N, void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
   return launch<1, true>(x, w, bias, sample_bias, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream);
+}
+
+int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, const float* residual, float* out, int dtype, int B, int H, int W,
+                           int Cin, int N, float out_scale, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
+  return launch<1, true, true>(x, w, bias, nullptr, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale);
 }
 
 }  // extern "C"

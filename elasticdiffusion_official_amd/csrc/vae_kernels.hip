@@ -1,0 +1,230 @@
+// vae_kernels.hip -- the fp32 VAE's ResnetBlock convolutions on the 16-bit MFMA pipe WITHOUT giving up fp32 accuracy (round 5).
+//
+// The reference keeps the VAE in fp32 on purpose (elastic_diffusion.py:328 encodes the pad strips outside autocast; :267-310 decodes
+// in fp32), and the parity gates hold this repo to that (latents 1e-4 / images 1e-3 against the reference's goldens).  Rounds 1-4 left
+// every VAE convolution to MIOpen's fp32 kernels: ~100 TFLOP/s on a chip whose fp32 matrix peak is 157 and whose 16-bit MFMA peak is
+// 2500 -- 8 % of the headline image (100 pad-strip encodes) and a quarter of the tiled 2048 x 2048 decode.
+//
+// Operand splitting: an fp32 value v is carried as two fp16 numbers, hi = fp16(v) and lo = fp16(v - hi): hi + lo = v to 2^-22 |v|
+// (11 + 11 significand bits).  With x = xh + xl and w = wh + wl,
+//     x . w = xh.wh + xl.wh + xh.wl  (+ xl.wl, 2^-22 relative: dropped)
+// and the three kept products, accumulated in fp32 by the MFMA, are ONE 16-bit convolution over 3 Cin channels:
+//     x'' = [xh | xl | xh]  (per pixel),  w'' = [wh | wh | wl]  (per tap)        =>  conv(x'', w'') = conv(x, w) to ~3e-7 relative.
+// So the existing implicit-GEMM main loop (gemm_kernels.hip, `ed_conv3x3_nhwc`) runs unchanged on channel-concatenated operands;
+// what is new is (a) this file: GroupNorm + SiLU over an fp32 NHWC activation that WRITES the split 3C-channel fp16 operand (the
+// activation after GroupNorm + SiLU is bounded by the affine parameters, so fp16's range is safe there -- which is why only the
+// ResnetBlock convolutions take this path and the stream-fed up / down-sampling convolutions stay with the library), and (b) an
+// fp32-output epilogue of the GEMM kernel (fp32 bias, fp32 residual, a power-of-two scale that undoes the weight pre-scaling which
+// keeps wl out of fp16's subnormal range): `ed_conv3x3_nhwc_f32out`.  Three MFMA passes at ~1 PFLOP/s are ~3.5 x the fp32 pipe.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "elastic_hip.h"
+
+namespace {
+
+#define GV_THREADS 256
+#define GV_UNROLL 4
+#define GV_MAXG 256
+
+__device__ __forceinline__ float silu32(float x) { return x / (1.0f + expf(-x)); }
+
+// ---- statistics: every thread owns one 4-channel column (cpg % 4 == 0: the column lies inside ONE group) and walks rows ----------
+// x [N, HW, C] fp32 (channels-last memory of a [N, C, H, W] tensor); partial [N, nchunks, G, 2] (sum, sum of squares), fixed summation
+// order: bit-reproducible.
+__global__ void __launch_bounds__(GV_THREADS)
+k_gn32_nhwc_partial(const float* __restrict__ x, float* __restrict__ partial, int C, int HW, int G, int rows_per_block) {
+  extern __shared__ float sh[];          // [row lanes][VC][2]
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int VC = C >> 2, cpg = C / G;
+  const int ncol = (VC + GV_THREADS - 1) / GV_THREADS;        // columns per thread (1 for C <= 1024)
+  const int R = ncol == 1 ? GV_THREADS / VC : 1;              // row lanes
+  const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
+  const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
+  const bool active = ncol == 1 ? (int)threadIdx.x < R * VC : true;
+  const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  const float* base = x + (int64_t)n * HW * C;
+  if (active) {
+    for (int j = 0; j < ncol; ++j) {
+      const int vc = my_c + j * GV_THREADS;
+      if (vc >= VC) break;
+      float s = 0.f, q = 0.f;
+      const float* col = base + (vc << 2);
+      const int64_t step = (int64_t)R * C;
+      int row = r0 + my_r;
+      for (; row + (GV_UNROLL - 1) * R < r1; row += GV_UNROLL * R) {
+        const float* p0 = col + (int64_t)row * C;
+        float4 v[GV_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GV_UNROLL; ++u) v[u] = *reinterpret_cast<const float4*>(p0 + u * step);
+#pragma unroll
+        for (int u = 0; u < GV_UNROLL; ++u) {
+          s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+          q += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+        }
+      }
+      for (; row < r1; row += R) {
+        const float4 v = *reinterpret_cast<const float4*>(col + (int64_t)row * C);
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      float* slot = sh + ((int64_t)my_r * VC + vc) * 2;
+      slot[0] = s, slot[1] = q;
+    }
+  }
+  __syncthreads();
+  float* dst = partial + ((int64_t)n * gridDim.x + chunk) * 2 * G;
+  const int cols_per_group = cpg >> 2;
+  for (int g = threadIdx.x; g < G; g += GV_THREADS) {
+    double s = 0.0, q = 0.0;
+    for (int vc = g * cols_per_group; vc < (g + 1) * cols_per_group; ++vc)
+      for (int r = 0; r < R; ++r) {
+        const float* slot = sh + ((int64_t)r * VC + vc) * 2;
+        s += (double)slot[0];
+        q += (double)slot[1];
+      }
+    dst[2 * g] = (float)s;
+    dst[2 * g + 1] = (float)q;
+  }
+}
+
+// ---- apply: y = [silu]((x - mean) rstd gamma + beta) in fp32, written as
+//   SPLIT = false: fp32 [N, HW, C]
+//   SPLIT = true : fp16 [N, HW, 3 C] = [hi | lo | hi] with hi = fp16(y), lo = fp16(y - hi)     (the A operand of ed_conv3x3_nhwc_f32out)
+template <bool ACT, bool SPLIT>
+__global__ void __launch_bounds__(GV_THREADS)
+k_gn32_nhwc_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                  const float* __restrict__ partial, void* __restrict__ out, int C, int HW, int G, int rows_per_block, double count,
+                  float eps) {
+  __shared__ double red[2 * GV_THREADS];
+  __shared__ float stats[2 * GV_MAXG];
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  {
+    const int parts = GV_THREADS / G > 0 ? GV_THREADS / G : 1;
+    const int g = threadIdx.x % G, part = threadIdx.x / G;
+    double s = 0.0, q = 0.0;
+    if (part < parts) {
+      const float* p = partial + (int64_t)n * nchunks * 2 * G + 2 * g;
+      for (int c = part; c < nchunks; c += parts) {
+        s += (double)p[(int64_t)c * 2 * G];
+        q += (double)p[(int64_t)c * 2 * G + 1];
+      }
+    }
+    red[2 * threadIdx.x] = s, red[2 * threadIdx.x + 1] = q;
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+      double ss = 0.0, qq = 0.0;
+      for (int k = 0; k < parts; ++k) {
+        ss += red[2 * (k * G + threadIdx.x)];
+        qq += red[2 * (k * G + threadIdx.x) + 1];
+      }
+      const double mean = ss / count;
+      double var = qq / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stats[2 * threadIdx.x] = (float)mean;
+      stats[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+  }
+  const int VC = C >> 2, cpg = C / G;
+  const int ncol = (VC + GV_THREADS - 1) / GV_THREADS;
+  const int R = ncol == 1 ? GV_THREADS / VC : 1;
+  const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
+  const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
+  if (ncol == 1 && (int)threadIdx.x >= R * VC) return;
+  const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+  const float* xb = x + (int64_t)n * HW * C;
+  for (int j = 0; j < ncol; ++j) {
+    const int vc = my_c + j * GV_THREADS;
+    if (vc >= VC) break;
+    const int c0 = vc << 2, g = c0 / cpg;
+    const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c0), bt = *reinterpret_cast<const float4*>(beta + c0);
+    const float a0 = rstd * gm.x, a1 = rstd * gm.y, a2 = rstd * gm.z, a3 = rstd * gm.w;
+    const float b0 = fmaf(-a0, mean, bt.x), b1 = fmaf(-a1, mean, bt.y), b2 = fmaf(-a2, mean, bt.z), b3 = fmaf(-a3, mean, bt.w);
+    auto norm = [&](const float4& v) {
+      float4 o;
+      o.x = fmaf(a0, v.x, b0), o.y = fmaf(a1, v.y, b1), o.z = fmaf(a2, v.z, b2), o.w = fmaf(a3, v.w, b3);
+      if (ACT) o.x = silu32(o.x), o.y = silu32(o.y), o.z = silu32(o.z), o.w = silu32(o.w);
+      return o;
+    };
+    auto store = [&](int64_t row, const float4& y) {
+      if (SPLIT) {
+        uint16_t* ob = reinterpret_cast<uint16_t*>(out) + ((int64_t)n * HW + row) * (3 * (int64_t)C) + c0;
+        const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
+        const _Float16 l0 = (_Float16)(y.x - (float)h0), l1 = (_Float16)(y.y - (float)h1), l2 = (_Float16)(y.z - (float)h2),
+                       l3 = (_Float16)(y.w - (float)h3);
+        uint2 hi, lo;
+        hi.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+        hi.y = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+        lo.x = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+        lo.y = (uint32_t)__builtin_bit_cast(uint16_t, l2) | ((uint32_t)__builtin_bit_cast(uint16_t, l3) << 16);
+        *reinterpret_cast<uint2*>(ob) = hi;
+        *reinterpret_cast<uint2*>(ob + C) = lo;
+        *reinterpret_cast<uint2*>(ob + 2 * C) = hi;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + ((int64_t)n * HW + row) * C + c0) = y;
+      }
+    };
+    const int64_t step = (int64_t)R * C;
+    int row = r0 + my_r;
+    for (; row + (GV_UNROLL - 1) * R < r1; row += GV_UNROLL * R) {
+      const float* p0 = xb + (int64_t)row * C + c0;
+      float4 v[GV_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GV_UNROLL; ++u) v[u] = *reinterpret_cast<const float4*>(p0 + u * step);
+#pragma unroll
+      for (int u = 0; u < GV_UNROLL; ++u) store(row + u * R, norm(v[u]));
+    }
+    for (; row < r1; row += R) store(row, norm(*reinterpret_cast<const float4*>(xb + (int64_t)row * C + c0)));
+  }
+}
+
+inline int done() { return (int)hipGetLastError(); }
+
+inline int gv_chunks(int C, int HW, int* rows_per_block) {
+  // ~64 K elements per block, at most 256 chunks per sample (every apply block re-reads its sample's [nchunks, G, 2] partial sums)
+  int rpb = (65536 + C - 1) / C;
+  if ((HW + rpb - 1) / rpb > 256) rpb = (HW + 255) / 256;
+  if (rpb < 1) rpb = 1;
+  *rows_per_block = rpb;
+  return (HW + rpb - 1) / rpb;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ed_groupnorm_nhwc_f32_workspace(int N, int C, int HW, int G) {
+  if (G <= 0 || C <= 0 || HW <= 0) return 0;
+  int rpb;
+  const int nchunks = gv_chunks(C, HW, &rpb);
+  return (int64_t)N * nchunks * G * 2 * (int64_t)sizeof(float);
+}
+
+int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW, int G,
+                          float eps, int act_silu, int split16, void* stream) {
+  if (N == 0) return 0;
+  if (N < 0 || G <= 0 || G > GV_MAXG || C % G != 0 || (C / G) % 4 != 0 || C > 4 * GV_THREADS * 4 || N > 65535 ||
+      (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)workspace) & 15u))
+    return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  int rpb;
+  const int nchunks = gv_chunks(C, HW, &rpb);
+  dim3 grid(nchunks, N);
+  const int VC = C / 4;
+  const size_t lds = sizeof(float) * 2 * (size_t)VC * (VC <= GV_THREADS ? GV_THREADS / VC : 1);
+  k_gn32_nhwc_partial<<<grid, GV_THREADS, lds, s>>>((const float*)x, workspace, C, HW, G, rpb);
+  const double count = (double)HW * (C / G);
+#define GV_APPLY(ACT, SPLIT)                                                                                                      \
+  k_gn32_nhwc_apply<ACT, SPLIT><<<grid, GV_THREADS, 0, s>>>((const float*)x, (const float*)gamma, (const float*)beta, workspace, \
+                                                            out, C, HW, G, rpb, count, eps)
+  if (act_silu && split16) GV_APPLY(true, true);
+  else if (act_silu) GV_APPLY(true, false);
+  else if (split16) GV_APPLY(false, true);
+  else GV_APPLY(false, false);
+#undef GV_APPLY
+  return done();
+}
+
+}  // extern "C"

@@ -71,6 +71,11 @@ def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=
     if _fusable(x) and (H * W) % 8 == 0 and (not tokens or cpg % 4 == 0):
         from . import ops
         return ops.groupnorm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, tokens=tokens)
+    if (VAE_SPLIT_CONV and FUSED_KERNELS and x.is_cuda and x.dtype == torch.float32 and not tokens and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last) and norm.weight.dtype == torch.float32):
+        from . import ops  # the channels-last fp32 VAE (VAE_SPLIT_CONV): the normalisation layers that do not feed a split convolution
+        if ops.groupnorm_nhwc_f32_ok(C, norm.num_groups):
+            return ops.groupnorm_nhwc_f32(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
     if (VAE_HIP_GROUPNORM and FUSED_KERNELS and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not tokens
             and (H * W) % 4 == 0 and norm.weight.dtype == torch.float32 and N * norm.num_groups <= 65535):
         from . import ops  # the fp32 VAE: split statistics + apply (+SiLU) instead of torch's one-block-per-group moments
@@ -99,6 +104,13 @@ VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_ro
 # bit.  Measured on the MI355X, each layout with its own MIOpen find (profiles/r4_s1_vae_layout_ab.jsonl): 8 decode tiles of
 # 128 x 128 latents 979 -> 760 ms, the 128 x 256 decode 202 -> 198 ms, 5 pad-strip encodes 54.9 -> 54.7 ms.
 VAE_NCHW_RESIDUAL = True
+# Round 5: the VAE's ResnetBlock convolutions (94 % of the encoder's and 71 % of the decoder's convolution FLOPs) on the 16-bit MFMA
+# pipe at fp32 accuracy: the activation after GroupNorm + SiLU and the weights are each carried as an fp16 (hi, lo) pair and
+# x.w = xh.wh + xl.wh + xh.wl is ONE ed_conv3x3_nhwc main loop over 3 Cin channels with an fp32 epilogue (csrc/vae_kernels.hip).  The
+# ResnetBlocks then pass channels-last fp32 activations to each other (the kernel's layout); the stream-fed up / down-sampling
+# convolutions, conv_in / conv_out and the mid-block attention stay with the fp32 libraries in NCHW (_to_nchw: one layout copy per block
+# boundary).  As accurate against fp64 as the library's fp32 convolution (tests/test_vae_split.py).
+VAE_SPLIT_CONV = True
 # A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
 for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
     if _name not in globals() or not isinstance(globals()[_name], bool):
@@ -142,6 +154,37 @@ def _hip_conv3x3(x, conv, shape_only=False):
     from . import ops
     B, C, H, W = x.shape
     return ops.conv3x3_wins(B, H, W, C, w.shape[0])
+
+
+def _to_nchw(x):
+    """The split VAE blocks (VAE_SPLIT_CONV) hand on channels-last fp32 activations; everything around them -- the stream-fed up / down-
+    sampling convolutions, the mid-block attention, conv_norm_out / conv_out -- runs NCHW, the layout the in-tree MIOpen find-db has
+    fp32 records for (a shape without a record costs a minutes-long find on first use).  One layout copy per block boundary."""
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _vae_split_ok(x, blk):
+    """Can this fp32 VAE ResnetBlock2D (no time embedding) run its two convolutions as split-fp16 MFMA convolutions on ``x``?"""
+    if not (VAE_SPLIT_CONV and FUSED_KERNELS and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and blk.time_emb_proj is None and blk.conv1.weight.dtype == torch.float32):
+        return False
+    from . import ops
+    B, cin, H, W = x.shape
+    cout = blk.conv1.out_channels
+    return (ops.groupnorm_nhwc_f32_ok(cin, blk.norm1.num_groups) and ops.groupnorm_nhwc_f32_ok(cout, blk.norm2.num_groups)
+            and cin % 64 == 0 and cout % 64 == 0 and H * W * 3 * max(cin, cout) * 2 < 2 ** 31 - 16)
+
+
+def _split_weight(conv):
+    """(split fp16 weight, 2^-k) of a Conv2d for ops.conv3x3_f32out, rebuilt when the weight changes"""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    hit = conv.__dict__.get("_split_w")
+    if hit is None or hit[0] != key:
+        from . import ops
+        hit = (key,) + ops.split_conv_weight(w)
+        conv.__dict__["_split_w"] = hit
+    return hit[1], hit[2]
 
 
 def layer_norm(norm, x):
@@ -207,6 +250,8 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
     def forward(self, x, temb=None):
+        if _vae_split_ok(x, self):
+            return self._forward_split(x)
         tb = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
         sc = self.conv_shortcut
         cout = self.conv1.out_channels
@@ -250,6 +295,36 @@ class ResnetBlock2D(nn.Module):
             return torch.baddbmm(h.view(N, cout, H * W), w, x.view(N, C, H * W)).view(N, cout, H, W)
         h = self.conv2(a)
         return (x if sc is None else sc(x)) + h
+
+
+def _resnet_forward_split(self, x):
+    """The fp32 VAE block with both 3x3 convolutions on the MFMA pipe (VAE_SPLIT_CONV): GroupNorm + SiLU write the split fp16 operand,
+    the convolution's fp32 epilogue adds the bias and (conv2) the block's residual.  Batches whose operand would exceed the kernel's
+    32-bit offsets are processed in slices (GroupNorm is per sample)."""
+    from . import ops
+    cl = torch.channels_last
+    if not x.is_contiguous(memory_format=cl):
+        x = x.contiguous(memory_format=cl)
+    B, cin, H, W = x.shape
+    cout = self.conv1.out_channels
+    per = H * W * 3 * max(cin, cout) * 2
+    nb = max(1, (2 ** 31 - 16) // per)
+    if B > nb:
+        return torch.cat([_resnet_forward_split(self, x[i:i + nb]) for i in range(0, B, nb)]).contiguous(memory_format=cl)
+    w1, s1 = _split_weight(self.conv1)
+    w2, s2 = _split_weight(self.conv2)
+    a = ops.groupnorm_nhwc_f32(x, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, silu=True, split=True)
+    h = ops.conv3x3_f32out(a, w1, self.conv1.bias, None, s1)
+    a = ops.groupnorm_nhwc_f32(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, silu=True, split=True)
+    sc = self.conv_shortcut
+    if sc is None:
+        res = x
+    else:   # 1x1 convolution = an fp32 GEMM over the NHWC view
+        res = F.linear(x.permute(0, 2, 3, 1), sc.weight.reshape(cout, cin), sc.bias).permute(0, 3, 1, 2)
+    return ops.conv3x3_f32out(a, w2, self.conv2.bias, res, s2)
+
+
+ResnetBlock2D._forward_split = _resnet_forward_split
 
 
 class Attention(nn.Module):
@@ -414,7 +489,7 @@ class Downsample2D(nn.Module):
 
     def forward(self, x):
         if self.padding == 0:  # VAE encoder: asymmetric pad (diffusers Downsample2D)
-            x = F.pad(x, (0, 1, 0, 1))
+            x = F.pad(_to_nchw(x), (0, 1, 0, 1))
         return self.conv(x)
 
 
@@ -424,6 +499,8 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
+        if x.dtype == torch.float32:
+            x = _to_nchw(x)  # the VAE decoder's upsampler: NCHW for MIOpen's fp32 solvers (the UNet's 16-bit activations stay channels-last)
         up = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if _hip_conv3x3(up, self.conv):
             from . import ops
@@ -689,7 +766,9 @@ class _VaeAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        h = group_norm_act(self.group_norm, x).view(B, C, H * W).transpose(1, 2)
+        h = group_norm_act(self.group_norm, x)
+        cl = not h.is_contiguous() and h.is_contiguous(memory_format=torch.channels_last)   # channels-last VAE (VAE_SPLIT_CONV)
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C) if cl else h.view(B, C, H * W).transpose(1, 2)
         if VAE_HIP_ATTENTION and h.is_cuda and h.dtype == torch.float32 and (H * W) % 4 == 0:
             # two fp32 library GEMMs around ed_softmax_rows: no AOTriton (Triton) kernel on the path
             from . import ops
@@ -697,7 +776,8 @@ class _VaeAttention(nn.Module):
         else:
             q, k, v = (f(h).unsqueeze(1) for f in (self.to_q, self.to_k, self.to_v))
             o = F.scaled_dot_product_attention(q, k, v).squeeze(1)
-        a = self.to_out[0](o).transpose(1, 2).reshape(B, C, H, W)
+        a = self.to_out[0](o)
+        a = a.view(B, H, W, C).permute(0, 3, 1, 2) if cl else a.transpose(1, 2).reshape(B, C, H, W)   # (cl: a view, no copy)
         return x + a if VAE_NCHW_RESIDUAL else a + x
 
 
@@ -708,7 +788,7 @@ class _VaeMid(nn.Module):
         self.attentions = nn.ModuleList([_VaeAttention(ch)])
 
     def forward(self, x):
-        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+        return self.resnets[1](self.attentions[0](_to_nchw(self.resnets[0](x))))
 
 
 class _EncBlock(nn.Module):
@@ -752,7 +832,7 @@ class _Encoder(nn.Module):
         x = self.conv_in(x)
         for b in self.down_blocks:
             x = b(x)
-        return self.conv_out(group_norm_act(self.conv_norm_out, self.mid_block(x), silu=True))
+        return self.conv_out(group_norm_act(self.conv_norm_out, _to_nchw(self.mid_block(x)), silu=True))
 
 
 class _Decoder(nn.Module):
@@ -773,7 +853,7 @@ class _Decoder(nn.Module):
         x = self.mid_block(self.conv_in(z))
         for b in self.up_blocks:
             x = b(x)
-        return self.conv_out(group_norm_act(self.conv_norm_out, x, silu=True))
+        return self.conv_out(group_norm_act(self.conv_norm_out, _to_nchw(x), silu=True))
 
 
 class DiagonalGaussian:

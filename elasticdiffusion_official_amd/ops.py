@@ -557,6 +557,74 @@ def groupnorm_f32(x, gamma, beta, groups, eps, silu=False):
     return out
 
 
+# ---- the fp32 VAE's ResnetBlock convolutions on split fp16 operands (csrc/vae_kernels.hip, gemm_kernels.hip OUT32) ------------------
+def groupnorm_nhwc_f32_ok(C, groups):
+    return C % groups == 0 and (C // groups) % 4 == 0 and groups <= 256 and C <= 4096
+
+
+def groupnorm_nhwc_f32(x, gamma, beta, groups, eps, silu=False, split=False):
+    """x [N,C,H,W] fp32 in channels_last memory -> GroupNorm(+SiLU) in fp32, returned as fp32 channels_last [N,C,H,W] or, with
+    ``split``, as the fp16 channels_last [N,3C,H,W] = [hi | lo | hi] operand of ``conv3x3_f32out`` (hi = fp16(y), lo = fp16(y - hi)).
+    See ed_groupnorm_nhwc_f32."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        _reject("groupnorm_nhwc_f32: x must be an fp32 [N,C,H,W] tensor on the MI355X; no CPU fallback")
+    N, C, H, W = x.shape
+    cl = torch.channels_last
+    if not x.is_contiguous(memory_format=cl):
+        _reject("groupnorm_nhwc_f32: x must be channels_last")
+    if not groupnorm_nhwc_f32_ok(C, groups):
+        _reject(f"groupnorm_nhwc_f32: unsupported C = {C}, groups = {groups}")
+    out = (torch.empty((N, 3 * C, H, W), dtype=torch.float16, device=x.device, memory_format=cl) if split
+           else torch.empty_like(x, memory_format=cl))
+    nbytes = _hip.lib().ed_groupnorm_nhwc_f32_workspace(N, C, H * W, groups)
+    ws = torch.empty(max(4, nbytes // 4), dtype=torch.float32, device=x.device)
+    TIMER.note_work("ed_groupnorm_nhwc_f32", nbytes=x.numel() * (4.0 + 4.0 + (6.0 if split else 4.0)))
+    _call("ed_groupnorm_nhwc_f32", x.data_ptr(), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"), out.data_ptr(),
+          _dev(ws, torch.float32, "workspace"), N, C, H * W, groups, float(eps), int(silu), int(split), _stream_of(x))
+    return out
+
+
+def split_conv_weight(w):
+    """fp32 Conv2d weight [N,Cin,3,3] -> (fp16 channels_last [N,3Cin,3,3] = [wh | wh | wl] of 2^k w, 2^-k): the B operand of
+    ``conv3x3_f32out`` for an A operand [xh | xl | xh].  2^k puts max |w| in [2^13, 2^14), so wl = fp16(2^k w - wh) stays out of
+    fp16's subnormal range for every weight above 2^-24 of the largest (exact: a power of two)."""
+    import math
+    wmax = float(w.detach().abs().max())
+    k = 0 if not (wmax > 0.0 and math.isfinite(wmax)) else max(-24, min(24, 13 - math.frexp(wmax)[1] + 1))
+    ws = w.detach().float() * (2.0 ** k)
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    return torch.cat([hi, hi, lo], dim=1).contiguous(memory_format=torch.channels_last), 2.0 ** -k
+
+
+def conv3x3_f32out_ok(B, H, W, Cin3, N):
+    M = B * H * W
+    return Cin3 % 64 == 0 and N % 8 == 0 and M * Cin3 * 2 < 2 ** 31 - 16 and N * 9 * Cin3 * 2 < 2 ** 31 - 16 and M < 2 ** 31
+
+
+def conv3x3_f32out(a, w, bias=None, residual=None, out_scale=1.0):
+    """a [B,Cin',H,W] fp16 and w [N,Cin',3,3] fp16 in channels_last memory (split operands: Cin' = 3 Cin, ``groupnorm_nhwc_f32(split=True)``
+    / ``split_conv_weight``) -> out_scale * conv2d(a, w, stride 1, padding 1) + bias + residual as fp32 channels_last [B,N,H,W]; bias fp32
+    [N], residual fp32 channels_last.  See ed_conv3x3_nhwc_f32out."""
+    if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dim() == 4 and a.dtype == torch.float16):
+        _reject("conv3x3_f32out: a must be an fp16 [B,C,H,W] tensor on the MI355X; no CPU fallback")
+    B, C3, H, W = a.shape
+    N = w.shape[0]
+    cl = torch.channels_last
+    if tuple(w.shape) != (N, C3, 3, 3) or w.dtype != torch.float16 or not conv3x3_f32out_ok(B, H, W, C3, N):
+        _reject(f"conv3x3_f32out: unsupported shape a {tuple(a.shape)} w {tuple(w.shape)}")
+    if not a.is_contiguous(memory_format=cl) or not w.is_contiguous(memory_format=cl):
+        _reject("conv3x3_f32out: a and w must be channels_last")
+    out = torch.empty((B, N, H, W), dtype=torch.float32, device=a.device, memory_format=cl)
+    if residual is not None and (residual.shape != out.shape or residual.dtype != torch.float32 or not residual.is_contiguous(memory_format=cl)):
+        _reject("conv3x3_f32out: residual must be an fp32 channels_last tensor of the output's shape")
+    TIMER.note_work("ed_conv3x3_nhwc_f32out", flops=2.0 * B * H * W * 9 * C3 * N,
+                    nbytes=2.0 * (B * H * W * C3 + 9 * C3 * N) + 4.0 * B * H * W * N * (2 if residual is not None else 1))
+    _call("ed_conv3x3_nhwc_f32out", a.data_ptr(), w.data_ptr(), _opt(bias, torch.float32, "bias"),
+          None if residual is None else residual.data_ptr(), out.data_ptr(), _DTYPE[torch.float16], B, H, W, C3, N, float(out_scale), _stream_of(a))
+    return out
+
+
 def softmax_rows_(x, scale=1.0):
     """x fp32 [..., cols] contiguous -> softmax(scale * x) over the last dim, IN PLACE (ed_softmax_rows)."""
     cols = x.shape[-1]

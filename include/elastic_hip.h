@@ -362,6 +362,29 @@ int ed_linear(const void* x, const void* w, const void* bias, const void* residu
 int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* sample_bias, const void* residual, void* out,
                     int dtype, int B, int H, int W, int Cin, int N, void* stream);
 
+/*
+ * ---- the fp32 VAE's ResnetBlock convolutions on split 16-bit operands (csrc/vae_kernels.hip + the fp32-output epilogue of the
+ * GEMM main loop; round 5).  The reference runs the VAE in fp32 (elastic_diffusion.py:267-310 decode, :327-364 pad-strip encodes,
+ * kept out of autocast at :328); these entry points keep fp32 accuracy (~3e-7 relative per convolution) on the 16-bit MFMA pipe:
+ * an fp32 value v is carried as hi = fp16(v), lo = fp16(v - hi), and  x.w = xh.wh + xl.wh + xh.wl  is ONE 16-bit convolution over
+ * 3 Cin channels, x'' = [xh | xl | xh] per pixel against w'' = [wh | wh | wl] per tap, accumulated in fp32 by the MFMA.
+ *
+ * ed_groupnorm_nhwc_f32 -- GroupNorm [+ SiLU] of an fp32 channels-last activation x [N, HW, C] (statistics in fp32 partial sums
+ *   combined in double, fixed order):  split16 = 0: out fp32 [N, HW, C];  split16 = 1: out fp16 [N, HW, 3 C] = [hi | lo | hi], the
+ *   A operand of ed_conv3x3_nhwc_f32out (after GroupNorm + SiLU the values are bounded by the affine parameters: fp16's range is
+ *   safe).  (C / G) % 4 == 0, G <= 256; workspace: ed_groupnorm_nhwc_f32_workspace bytes; pointers 16-byte aligned.
+ * ed_conv3x3_nhwc_f32out -- ed_conv3x3_nhwc's main loop with an fp32 epilogue:
+ *   out[b,y,x,n] = out_scale * sum_{dy,dx,c} x[b,y+dy,x+dx,c] w[n,dy,dx,c] + bias[n] + residual[b,y,x,n]      (no 16-bit rounding)
+ *   x fp16 [B,H,W,Cin'] and w fp16 [N,3,3,Cin'] (Cin' = 3 Cin for split operands; any Cin' % 64 == 0 works), bias fp32 [N] or NULL,
+ *   residual fp32 [B,H,W,N] or NULL, out fp32 [B,H,W,N]; dtype must be ED_F16; out_scale: a power of two that undoes the
+ *   pre-scaling of the split weights (which keeps wl out of fp16's subnormal range).  N % 8 == 0, 32-bit operand offsets as above.
+ */
+int64_t ed_groupnorm_nhwc_f32_workspace(int N, int C, int HW, int G);
+int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW, int G,
+                          float eps, int act_silu, int split16, void* stream);
+int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, const float* residual, float* out, int dtype, int B, int H, int W,
+                           int Cin, int N, float out_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

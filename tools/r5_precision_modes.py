@@ -46,6 +46,11 @@ MODES = {
     "mixed_out16": {"w", "act", "attn", "out"},
     "mixed_out32": {"w", "act", "attn"},
     "operands_only_no_w": {"act", "attn"},
+    # candidates for a tolerance-meeting mode on the MFMA pipe: split (hi, lo) operands remove a rounding class entirely
+    "attn_o": {"attn_o"},                              # only the 16-bit store of every attention's output
+    "split_x3_fp16_attention": {"attn", "attn_o"},     # activations AND weights split (3 MFMA passes), fp32 stream; fp16 flash attention in / out
+    "split_x2_fp16_attention": {"w", "attn", "attn_o"},   # activations split (2 passes), fp16 weights
+    "split_x2_attention_f32out": {"w", "attn"},
 }
 
 
@@ -76,7 +81,7 @@ class Rounding(TorchFunctionMode):
             s = (q @ k.transpose(-1, -2)) * q.shape[-1] ** -0.5
             p = torch.exp(s - s.amax(-1, keepdim=True))
             o = (self.q(p, "attn") @ v) / p.sum(-1, keepdim=True)       # the kernels pack P to 16 bits for the second MFMA; l is an fp32 sum
-            return self.q(o, "out")
+            return self.q(self.q(o, "out"), "attn_o")
         y = func(*args, **kwargs)
         if func in ADDS and torch.is_tensor(y) and y.dtype == torch.float32 and y.dim() >= 2:
             return self.q(y, "stream")
