@@ -37,4 +37,4 @@ for f in ("bench_headline", "bench_cfg4"):
     except Exception as e:
         print(f, "failed", e)
 PY
-tail -3 $O/bench_headline.err $O/bench_cfg4.err
+tail -q -n 3 $O/bench_headline.err $O/bench_cfg4.err
