@@ -425,7 +425,7 @@ def main():
     rows_share = (pipe.sharder.rows_computed, pipe.sharder.rows_total)
 
     # ---- informative extras, all OUTSIDE the timed region and never `value` ------------------------------------------
-    layouts, cached_s, extras_error = {}, None, None
+    layouts, cached_s, two_s, extras_error = {}, None, None, None
     if not args.no_extras:
         try:  # an informative extra must never cost the run its headline line
             if world == 1 and not args.cache_backgrounds:
@@ -434,6 +434,11 @@ def main():
                 cached_s = timed(pipe, 2001, 1, 1, 1, 0)
                 pipe.cache_backgrounds = False
                 pipe._frame_cache.clear()
+            if world == 1 and m == 1 and n_timed >= 2 and cn_scale is None:
+                # two images in flight on the one GPU (their pending model calls fused: 40- and 12-row forwards fill the chip better):
+                # the throughput the N >= 2 layouts' in-flight policy would give at N = 1, at twice the latency
+                run_images(pipe, [3000, 3001], 2)
+                two_s = timed(pipe, 3002, 2, 2, 1, 0) / 2.0
             if world > 1:
                 # the same N GPUs in the other layouts, so that a scaling record cannot pass one off as another
                 alts = []
@@ -512,7 +517,7 @@ def main():
             # PMC traffic is measured offline (rocprofv3 --pmc passes, profiles/): one file per workload, newest round first;
             # a workload without a committed PMC pass reports traffic null rather than another workload's bytes
             pmc, pmc_file = None, None
-            for fname in (f"r4_unet_pmc_{args.workload}.json", "r4_unet_pmc.json", f"r3_unet_pmc_{args.workload}.json",
+            for fname in (f"r5_unet_pmc_{args.workload}.json", "r5_unet_pmc.json", f"r4_unet_pmc_{args.workload}.json", "r4_unet_pmc.json", f"r3_unet_pmc_{args.workload}.json",
                           "r3_unet_pmc.json", "r2_unet_pmc.json"):
                 doc = load_profile_json(fname)
                 if doc and doc.get("workload", "sdxl_1024x2048") == args.workload and dom in doc.get("kernels", {}):
@@ -562,6 +567,7 @@ def main():
             "rows_computed_over_rows_total_rank0": list(rows_share),
             "layouts": layouts,
             "extras": {"images_per_s_with_background_cache": None if cached_s is None else round(1.0 / cached_s, 5),
+                       "images_per_s_two_images_in_flight": None if two_s is None else round(1.0 / two_s, 5),
                        "error": extras_error,
                        "note": "optional modes measured after the timed region; never the headline"},
             "phase_ms_last_image": {k: round(v, 1) for k, v in phases.items()},

@@ -64,11 +64,15 @@ def run(batch, fam, dtype="fp16"):
 
 
 def short(name):
+    if "k_geglu_persist" in name:
+        return "k_geglu_persist"
     for key in ("k_gemm_8phase", "k_flash_attn", "k_add_layernorm", "k_gn", "Cijk", "ck::", "k_bias_residual", "k_tokens_add", "elementwise",
                 "CatArray", "upsample", "k_geglu", "miopen", "naive_conv", "igemm"):
         if key in name:
             if key == "k_gemm_8phase":
-                return "k_gemm_8phase" + ("<geglu>" if ", 0, false>" in name else "<conv>" if ", 1, true>" in name else "<linear>")
+                args = [v.strip() for v in name.split("k_gemm_8phase<", 1)[1].split(">", 1)[0].split(",")]   # <T, EPI, CONV, ADD, OUT32, TWO>
+                conv = len(args) > 2 and args[2] == "true"
+                return "k_gemm_8phase" + ("<geglu>" if args[1] == "0" else ("<conv long-K>" if args[-1] == "true" and len(args) > 5 else "<conv>") if conv else "<linear>")
             return key
     return name.split("(")[0][-40:]
 

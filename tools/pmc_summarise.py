@@ -27,9 +27,20 @@ ENTRY = {"k_flash_attn_fwd": "ed_flash_attention", "k_flash_attn_pipe": "ed_flas
 
 
 def entry_of(kernel):
-    m = re.search(r"k_gemm_8phase<[^,]*, *(\d), *(true|false)", kernel)   # one main loop, three entry points (EPI, CONV)
+    m = re.search(r"k_gemm_8phase<([^>]*)>", kernel)   # one main loop: <T, EPI, CONV, ADD, OUT32, TWO> (round 5; defaults may be elided)
     if m:
-        return "ed_geglu_gemm" if m.group(1) == "0" else ("ed_conv3x3_nhwc" if m.group(2) == "true" else "ed_linear")
+        args = [a.strip() for a in m.group(1).split(",")]
+        epi, conv = args[1], args[2] == "true"
+        out32 = len(args) > 4 and args[4] == "true"
+        if epi == "0":
+            return "ed_geglu_gemm"
+        return "ed_conv3x3_nhwc_f32out" if (conv and out32) else ("ed_conv3x3_nhwc" if conv else "ed_linear")
+    if "k_geglu_persist" in kernel:
+        return "ed_geglu_gemm"
+    if "k_gn32_nhwc_partial" in kernel:
+        return "ed_groupnorm_nhwc_f32[partial]"
+    if "k_gn32_nhwc_apply" in kernel:
+        return "ed_groupnorm_nhwc_f32[apply]"
     for k, v in ENTRY.items():  # dict order: longer, more specific names come before their prefixes
         if re.search(k + r"(?![a-z])", kernel):
             return v
