@@ -265,6 +265,8 @@ def main():
                          "that meets BASELINE.json's 1e-3), timed, and the rel-L2 of the benchmarked 16-bit latent against it -- "
                          "`tolerance.fp32_unet_same_workload`, ~100 s.  auto: on for the headline workload at N = 1 with at least "
                          "2 timed images (the driver's command), off otherwise")
+    ap.add_argument("--fp32-leg-seeds", type=int, default=1,
+                    help="how many of the last timed images (one seed each) the fp32 leg repeats; 1 (default) keeps the leg at ~2 min")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: initialise RCCL with one rank and send every sharded batch through the all-gather path "
                          "(what a 1-GPU box can exercise of the multi-GPU exchange)")
@@ -352,7 +354,7 @@ def main():
         cond_img = torch.cat([yy, xx, 0.5 * (yy + xx)], dim=1).contiguous()
         kw.update(condition_image=cond_img, controlnet_conditioning_scale=cn_scale)
     prompt, negative = "An astronaut riding a corgi on the moon", "blurry, ugly, poorly drawn, deformed"
-    state = {"imgs": None, "latency": None}
+    state = {"imgs": None, "latency": None, "keep_latents": None}
 
     def run_images(p, seeds, in_flight):
         """``len(seeds)`` images through pipeline ``p`` (latents + decode); all ranks of p's shard group call this with
@@ -363,6 +365,8 @@ def main():
                 p.seed_everything(sd_)
                 state["imgs"], _ = p.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt",
                                                     progress=lambda it: it, **kw)
+                if state.get("keep_latents") is not None:    # (512 KiB device copy, asynchronous: the fp32 leg compares against it)
+                    state["keep_latents"][sd_] = p.last_latents.detach().clone()
             return
         jobs = [dict(prompts=prompt, negative_prompts=negative, seed=sd_, condition_image=cond_img) for sd_ in seeds]
 
@@ -413,11 +417,16 @@ def main():
     if timing:
         fence()
         ops.TIMER.start()
+    if world == 1 and m == 1:
+        state["keep_latents"] = {}
     elapsed = timed(pipe, 0, n_timed, m, n_groups, group_id)
     ktimes = ops.TIMER.stop() if timing else {}
     lat_timed = state["latency"]
     # the last timed image's latent (seed n_timed - 1), for the live comparison with the fp32 UNet after the timed region
-    z16_last = pipe.last_latents.detach().clone() if (world == 1 and m == 1 and pipe.last_latents is not None) else None
+    n_cmp = max(1, min(args.fp32_leg_seeds, n_timed))
+    z16_last = ({sd_: z.detach().clone() for sd_, z in (state["keep_latents"] or {}).items() if sd_ >= n_timed - n_cmp and z is not None}
+                or None)
+    state["keep_latents"] = None
     finite = bool(torch.isfinite(state["imgs"]).all()) if state["imgs"] is not None else True
     phases = pipe.phase_times()
     host_ms = {k: round(1e3 * v, 1) for k, v in pipe.host_s.items()}
@@ -465,7 +474,7 @@ def main():
                                           and n_timed >= 2 and not args.no_extras)
     if want_fp32 and world == 1 and m == 1 and dtype != torch.float32 and not args.small and z16_last is not None:
         try:
-            fp32_live = fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, n_timed - 1, z16_last, args.dtype)
+            fp32_live = fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, z16_last, args.dtype)
         except Exception as e:  # noqa: BLE001 -- never costs the run its headline line
             fp32_live = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -620,7 +629,7 @@ def parity_leg(dev, dtype_name="bf16"):
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, seed, z16, dtype_name):
+def fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, z16_by_seed, dtype_name):
     """ONE image of the benchmarked workload with the fp32 UNet (same seeded weights before the 16-bit cast, same VAE object, same
     seed as the last timed image), after a 2-timestep warm-up image that captures its hipGraphs and pays MIOpen's first-use searches: what north_star's 1e-3 costs on this
     chip, on the driver's own clock, and how far the benchmarked 16-bit latent is from it at FULL width over all 50 timesteps (the
@@ -631,19 +640,25 @@ def fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, seed, z16, dty
     p32.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", progress=lambda it: it,
                        **dict(kw, num_inference_steps=2))     # (2 timesteps: both phase batches, 20 and 6 rows, are captured and warm)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    p32.seed_everything(seed)
-    imgs, _ = p32.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", progress=lambda it: it, **kw)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    z32 = p32.last_latents.double()
-    rel = float((z16.double() - z32).norm() / z32.norm())
-    out = {"images_per_s": round(1.0 / el, 5), "s_per_image": round(el, 2), "images": 1, "seed": seed,
+    rels, el, finite = {}, 0.0, True
+    for seed in sorted(z16_by_seed, reverse=True):     # the last timed image first
+        t0 = time.perf_counter()
+        p32.seed_everything(seed)
+        imgs, _ = p32.generate_image(prompt, negative, tiled_decoder=wl["tiled"], output_type="pt", progress=lambda it: it, **kw)
+        torch.cuda.synchronize()
+        el += time.perf_counter() - t0
+        z32 = p32.last_latents.double()
+        rels[seed] = float(f"{float((z16_by_seed[seed].double() - z32).norm() / z32.norm()):.4e}")
+        finite = finite and bool(torch.isfinite(imgs).all())
+    el /= len(rels)
+    seed, rel = max(rels), rels[max(rels)]
+    out = {"images_per_s": round(1.0 / el, 5), "s_per_image": round(el, 2), "images": len(rels), "seed": seed,
+           f"{dtype_name}_latent_vs_fp32_latent_rel_l2_by_seed": {str(k): v for k, v in sorted(rels.items())},
            "unet": "fp32 weights and activations, plain torch ops (hipBLASLt / MIOpen fp32), hipGraph replay",
            "meets": "1e-3 rel-L2 vs the reference CPU path (fp32_model_vs_reference_cpu_path above; the fp32 loop is gated at 1e-3 "
                     "against the oracle in tests/test_real_arch_parity.py)",
            f"{dtype_name}_latent_vs_fp32_latent_rel_l2_full_width_{kw['num_inference_steps']}_steps": float(f"{rel:.4e}"),
-           "finite": bool(torch.isfinite(imgs).all()), "graphs": p32._runner.stats(),
+           "finite": finite, "graphs": p32._runner.stats(),
            "source": "measured live by this run, after the timed region", "leg_seconds": round(time.perf_counter() - t_build, 1)}
     del p32
     torch.cuda.empty_cache()

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ed_geglu_gemm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "ed_linear": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "ed_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_split_f32_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ed_groupnorm_nhwc_f32_workspace": [_i, _i, _i, _i],
     "ed_groupnorm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ed_conv3x3_nhwc_f32out": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],

@@ -180,6 +180,49 @@ k_gn32_nhwc_apply(const float* __restrict__ x, const float* __restrict__ gamma, 
   }
 }
 
+// ---- split of a raw fp32 channels-last activation (no normalisation in front of it: the decoder's upsampler convolutions) -----------
+// x fp32 [N, H, W, C] -> out fp16 [N, U H, U W, 3 C] = [hi | lo | hi], U = 1 or 2 (nearest-neighbour 2x upsampling folded into the write:
+// every input pixel lands on its U x U output pixels).  The stream is not bounded by an affine map, so hi SATURATES at fp16's largest
+// finite value instead of overflowing: hi = fp16(clamp(v, +-65504)), lo = fp16(v - hi) -- hi + lo then represents |v| up to 1.3e5 and
+// degrades gracefully above 65504 (lo alone carries the excess with 11 bits) instead of producing inf - inf.
+template <int U>
+__global__ void __launch_bounds__(256)
+k_split32_nhwc(const float* __restrict__ x, uint16_t* __restrict__ out, int C, int H, int W, int64_t n_vec) {
+  const int VC = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / VC;
+    const int c0 = (int)(i - pix * VC) << 2;
+    const float4 v = *reinterpret_cast<const float4*>(x + pix * C + c0);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    uint32_t hw[2], lw[2];
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      uint16_t hb[2], lb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float c = fminf(fmaxf(f[e + j], -65504.f), 65504.f);
+        const _Float16 h = (_Float16)c;
+        const _Float16 l = (_Float16)(f[e + j] - (float)h);
+        hb[j] = __builtin_bit_cast(uint16_t, h), lb[j] = __builtin_bit_cast(uint16_t, l);
+      }
+      hw[e >> 1] = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
+      lw[e >> 1] = (uint32_t)lb[0] | ((uint32_t)lb[1] << 16);
+    }
+    const uint2 hi = {hw[0], hw[1]}, lo = {lw[0], lw[1]};
+    const int64_t n = pix / ((int64_t)H * W), rem = pix - n * (int64_t)H * W;
+    const int y = (int)(rem / W), xx = (int)(rem - (int64_t)y * W);
+#pragma unroll
+    for (int dy = 0; dy < U; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < U; ++dx) {
+        uint16_t* ob = out + ((n * (U * H) + (U * y + dy)) * (int64_t)(U * W) + (U * xx + dx)) * (3 * (int64_t)C) + c0;
+        *reinterpret_cast<uint2*>(ob) = hi;
+        *reinterpret_cast<uint2*>(ob + C) = lo;
+        *reinterpret_cast<uint2*>(ob + 2 * C) = hi;
+      }
+  }
+}
+
 inline int done() { return (int)hipGetLastError(); }
 
 inline int gv_chunks(int C, int HW, int* rows_per_block) {
@@ -224,6 +267,19 @@ int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, vo
   else if (split16) GV_APPLY(false, true);
   else GV_APPLY(false, false);
 #undef GV_APPLY
+  return done();
+}
+
+int ed_split_f32_nhwc(const void* x, void* out, int N, int C, int H, int W, int upsample2x, void* stream) {
+  if (N == 0) return 0;
+  if (N < 0 || C <= 0 || C % 4 != 0 || H <= 0 || W <= 0 || (((uintptr_t)x | (uintptr_t)out) & 15u) || ((3 * C * 2) % 8) != 0)
+    return (int)hipErrorInvalidValue;
+  const int64_t n_vec = (int64_t)N * H * W * (C / 4);
+  int64_t blocks = (n_vec + 255) / 256;
+  if (blocks > 65536 * 16) blocks = 65536 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  if (upsample2x) k_split32_nhwc<2><<<(unsigned)blocks, 256, 0, s>>>((const float*)x, (uint16_t*)out, C, H, W, n_vec);
+  else k_split32_nhwc<1><<<(unsigned)blocks, 256, 0, s>>>((const float*)x, (uint16_t*)out, C, H, W, n_vec);
   return done();
 }
 

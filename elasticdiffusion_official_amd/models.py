@@ -498,9 +498,28 @@ class Upsample2D(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(ch, ch, 3, padding=1)
 
+    def _split_ok(self, x):
+        """fp32 VAE, channels % 64 == 0, and ONE sample's upsampled split operand within the kernel's 32-bit offsets (the 1024 x 2048
+        decode's last upsampler -- [1, 768, 1024, 2048] fp16 = 3.2 GB -- is not: it stays with the library)"""
+        if not (VAE_SPLIT_CONV and FUSED_KERNELS and x.is_cuda and x.dim() == 4 and self.conv.weight.dtype == torch.float32):
+            return False
+        B, C, H, W = x.shape
+        return C % 64 == 0 and 4 * H * W * 3 * C * 2 < 2 ** 31 - 16     # per sample; larger batches are processed in slices
+
     def forward(self, x):
         if x.dtype == torch.float32:
-            x = _to_nchw(x)  # the VAE decoder's upsampler: NCHW for MIOpen's fp32 solvers (the UNet's 16-bit activations stay channels-last)
+            if self._split_ok(x):
+                # the VAE decoder's upsampler on the MFMA pipe (VAE_SPLIT_CONV): the raw stream is split with a saturating hi and upsampled
+                # in one pass, the convolution is the same split-operand main loop as the ResnetBlocks'; channels-last in and out
+                from . import ops
+                w, sc = _split_weight(self.conv)
+                cl = torch.channels_last
+                x = x.contiguous(memory_format=cl)
+                B, C, H, W = x.shape
+                nb = max(1, (2 ** 31 - 16) // (4 * H * W * 3 * C * 2))
+                outs = [ops.conv3x3_f32out(ops.split_f32(x[i:i + nb], upsample2x=True), w, self.conv.bias, None, sc) for i in range(0, B, nb)]
+                return outs[0] if len(outs) == 1 else torch.cat(outs).contiguous(memory_format=cl)
+            x = _to_nchw(x)  # NCHW for MIOpen's fp32 solvers (the UNet's 16-bit activations stay channels-last)
         up = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if _hip_conv3x3(up, self.conv):
             from . import ops

@@ -584,6 +584,24 @@ def groupnorm_nhwc_f32(x, gamma, beta, groups, eps, silu=False, split=False):
     return out
 
 
+def split_f32(x, upsample2x=False):
+    """x [N,C,H,W] fp32 in channels_last memory -> the fp16 channels_last [N,3C,UH,UW] = [hi | lo | hi] operand of ``conv3x3_f32out`` for a
+    raw (un-normalised) activation, U = 2 with ``upsample2x`` (nearest-neighbour upsampling folded in).  hi saturates at fp16's largest
+    finite value.  See ed_split_f32_nhwc."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
+        _reject("split_f32: x must be an fp32 [N,C,H,W] tensor on the MI355X; no CPU fallback")
+    N, C, H, W = x.shape
+    cl = torch.channels_last
+    if not x.is_contiguous(memory_format=cl) or C % 4:
+        _reject("split_f32: x must be channels_last with C % 4 == 0")
+    u = 2 if upsample2x else 1
+    out = torch.empty((N, 3 * C, u * H, u * W), dtype=torch.float16, device=x.device, memory_format=cl)
+    TIMER.note_work("ed_split_f32_nhwc", nbytes=x.numel() * (4.0 + 6.0 * u * u))
+    _LAUNCH["device"] = x.device
+    _call("ed_split_f32_nhwc", x.data_ptr(), out.data_ptr(), N, C, H, W, int(bool(upsample2x)), _stream())
+    return out
+
+
 def split_conv_weight(w):
     """fp32 Conv2d weight [N,Cin,3,3] -> (fp16 channels_last [N,3Cin,3,3] = [wh | wh | wl] of 2^k w, 2^-k): the B operand of
     ``conv3x3_f32out`` for an A operand [xh | xl | xh].  2^k puts max |w| in [2^13, 2^14), so wl = fp16(2^k w - wh) stays out of

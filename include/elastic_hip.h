@@ -378,7 +378,12 @@ int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* 
  *   x fp16 [B,H,W,Cin'] and w fp16 [N,3,3,Cin'] (Cin' = 3 Cin for split operands; any Cin' % 64 == 0 works), bias fp32 [N] or NULL,
  *   residual fp32 [B,H,W,N] or NULL, out fp32 [B,H,W,N]; dtype must be ED_F16; out_scale: a power of two that undoes the
  *   pre-scaling of the split weights (which keeps wl out of fp16's subnormal range).  N % 8 == 0, 32-bit operand offsets as above.
+ * ed_split_f32_nhwc -- the same (hi, lo) split for a RAW fp32 channels-last activation x [N, H, W, C] (the VAE decoder's upsampler
+ *   convolutions, whose input is the un-normalised stream): out fp16 [N, U H, U W, 3 C] = [hi | lo | hi], U = 2 with upsample2x (nearest-
+ *   neighbour upsampling folded into the write), else 1.  hi saturates at +-65504 instead of overflowing (hi + lo then carries |v| up to
+ *   1.3e5, with lo's 11 bits above 65504).  C % 4 == 0; pointers 16-byte aligned.
  */
+int ed_split_f32_nhwc(const void* x, void* out, int N, int C, int H, int W, int upsample2x, void* stream);
 int64_t ed_groupnorm_nhwc_f32_workspace(int N, int C, int HW, int G);
 int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW, int G,
                           float eps, int act_silu, int split16, void* stream);
