@@ -677,10 +677,12 @@ def tolerance_statement(dtype_name, fp32_live=None):
           "benchmarked_dtype": dtype_name,
           "bar_16bit": "per-timestep rel-L2 vs the fp32 oracle <= 1.25 x (+ 2e-4) that of the reference's call pattern in the reference's "
                        "own GPU arithmetic, fp32 weights under torch.autocast (tests/realarch.gate_16bit; tests/test_real_arch_parity.py)",
-          "why_no_16bit_unet_meets_1e-3": "profiles/r5_precision_attribution.json: of the 1.3e-3 one fp16 forward errs by at full width, "
-                                          "9.2e-4 is the rounding of the MFMA operands (weights 6.7e-4, activations 6.4e-4) that "
-                                          "torch.autocast imposes on the reference's own GPU path too; an fp32 residual stream "
-                                          "would remove at most 30 %",
+          "where_the_16bit_error_comes_from": "profiles/r5_precision_attribution.json: of the 1.3e-3 one fp16 forward errs by at full width, "
+                                              "9.2e-4 is the rounding of the MFMA operands (weights 6.7e-4, activations 6.4e-4) that "
+                                              "torch.autocast imposes on the reference's own GPU path too; an fp32 residual stream would "
+                                              "remove at most 30 %.  Over the full 50-step schedule at full width the fp16 latent ends "
+                                              "8.9-9.0e-4 from the fp32 loop's (fp32_unet_same_workload below, measured live; five seeds "
+                                              "in profiles/) -- the 2-step reduced-width loops of this block overstate a full schedule",
           "evidence": "profiles/r3_precision.json"}
     if loop.get(dtype_name):
         st["measured_16bit_vs_fp32_oracle_max"] = max(loop[dtype_name])
