@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from elasticdiffusion_official_amd.sharding import RowSharder, row_partition
-from tests.procs import join_all
+from tests.procs import join_all, single_thread
 
 
 def _free_port():
@@ -32,6 +32,7 @@ def _model(x, text, pooled, cond):
 
 
 def _worker(rank, world, port, n_rows_list, ret):
+    single_thread()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -92,6 +93,7 @@ def test_single_process_is_identity():
 
 
 def _group_worker(rank, world, port, g, ret):
+    single_thread()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -121,6 +123,7 @@ def test_sub_groups_shard_independently():
 
 
 def _mismatch_worker(rank, world, port, ret):
+    single_thread()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -157,6 +160,7 @@ def test_row_shape_disagreement_is_an_error_not_a_hang():
 
 
 def _forced_worker(port, ret):
+    single_thread()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:

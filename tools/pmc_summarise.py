@@ -47,6 +47,11 @@ def entry_of(kernel):
     return None
 
 
+workload = "sdxl_1024x2048"
+if "--workload" in sys.argv:
+    i = sys.argv.index("--workload")
+    workload = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 out_path, dirs = sys.argv[1], sys.argv[2:]
 vals = defaultdict(lambda: defaultdict(list))
 for d in dirs:
@@ -68,6 +73,7 @@ for e, counters in vals.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in r and "SQ_BUSY_CU_CYCLES_mean" in r and r["SQ_BUSY_CU_CYCLES_mean"]:
         r["mfma_busy_over_cu_busy"] = round(r["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / r["SQ_BUSY_CU_CYCLES_mean"], 4)
     res[e] = r
-json.dump({"workload": "sdxl_1024x2048", "note": __doc__.strip().split("usage")[0].strip() + " Launch mix: one phase-A (20-row) and one phase-B (6-row) "
-                   "SDXL forward of the 1024x2048 workload (tools/pmc_unet.py).", "kernels": res}, open(out_path, "w"), indent=1)
+json.dump({"workload": workload, "note": __doc__.strip().split("usage")[0].strip() + (" Launch mix: one phase-A (20-row) and one phase-B (6-row) "
+                   "SDXL forward of the 1024x2048 workload (tools/pmc_unet.py)." if workload == "sdxl_1024x2048" else
+                   f" Launch mix: the second of two eager denoising timesteps of bench.py's workload {workload} (tools/pmc_workload.py)."), "kernels": res}, open(out_path, "w"), indent=1)
 print(json.dumps({k: {c: round(v, 1) if isinstance(v, float) else v for c, v in r.items()} for k, r in res.items()}, indent=1))
