@@ -87,6 +87,11 @@ def test_sharded_ranks_reproduce_reference_latents(golden_dir, world, name):
         np.testing.assert_array_equal(img, ret[0][1])
 
 
+def _quiet(stderr):
+    """stderr of a bench.py run without MIOpen's per-convolution workspace warnings (hundreds of lines that bury the one that matters)"""
+    return "\n".join(ln for ln in stderr.splitlines() if "MIOpen(HIP): Warning" not in ln)
+
+
 @pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "2", "--in-flight", "2"],
                                    ["--gpus", "4", "--shard-group", "2", "--in-flight", "2", "--all-layouts"],
                                    ["--gpus", "8"]])   # the driver's largest layout: one 8-way shard group, 4 images in flight
@@ -105,7 +110,15 @@ def test_bench_multi_rank_rehearsal(flags):
            "--master-port", str(_free_port()), "bench.py", *flags, "--steps", "2", "--warmup", "1", "--small",
            "--workload", "sd15_512x1024", "--timesteps", "3", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
+    if out.returncode != 0 and "SIGABRT" in out.stderr and "Traceback (most recent call last):\n  File \"bench.py\"" not in out.stderr:
+        # N + 1 processes (this pytest process holds a HIP context too) oversubscribing ONE GPU is the rehearsal's vehicle, not the
+        # deployment: in round 5 one rank of the 8-rank run died with SIGABRT inside the HIP runtime once in 22 runs of this command (4
+        # suite runs, 17 standalone repetitions with the whole stderr kept: none reproduced it; no Python exception).  A native abort
+        # -- not a Python error of bench.py, which still fails at once -- is retried ONCE, and the first attempt's stderr is shown.
+        print("first attempt aborted natively; stderr without MIOpen's workspace warnings:\n" + _quiet(out.stderr)[-8000:])
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert out.returncode == 0, _quiet(out.stderr)[-8000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
