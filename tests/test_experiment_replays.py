@@ -1,4 +1,5 @@
-"""CPU: the lane-level replays that stand behind the round-5 experiments (tools/gemm_persist, tools/gemm_sched, tools/attn16) keep
+"""CPU: the lane-level replays that stood behind the round-4/5 experiments (tools/gemm_persist, tools/gemm_sched, tools/attn16 -- folded into the
+product in round 5 and removed; git history up to 24deb02) keep
 passing -- they are what let those kernels run correctly on their first GPU launch, and what the patches in tools/r5_patches cite."""
 import os
 import sys

@@ -372,3 +372,39 @@ def test_pipelined_attention_schedule_emulation():
         assert np.abs(got - emu.reference(sc, v, 1.0)).max() < 1e-12
         slow_total += slow6
     assert slow_total > 0   # the slow path was exercised
+
+
+def test_round5_shape_policies_and_graph_keys():
+    """Host-side decisions added in round 5 (ADVICE r4 + the VAE split path), CPU only: the GEGLU GEMM's grid policy, the split-weight
+    preparation at its edges, the per-shape gates of the split VAE path, and the hipGraph key that separates fresh side inputs."""
+    import math
+    import torch
+    from elasticdiffusion_official_amd import models as M, ops
+    from elasticdiffusion_official_amd.graphs import GraphedForward
+    # GEGLU: the fused pair is used only where the grid fills the chip (the same main loop loses 2.4x on a 25-tile grid)
+    assert ops.geglu_gemm_wins(20480, 1280, 5120) and ops.geglu_gemm_wins(6144, 1280, 5120)
+    assert not ops.geglu_gemm_wins(256, 1280, 5120) and ops.geglu_gemm_ok(256, 1280, 5120)      # 1 x 40 tiles: the kernel takes it, the model does not
+    assert not ops.geglu_gemm_wins(20480, 1280, 5000)                                            # I % 128 != 0
+    # split weights: scale is a power of two, wl never subnormal for the bulk, all-zero and huge weights survive
+    for w in (torch.zeros(8, 64, 3, 3), torch.full((8, 64, 3, 3), 3.0e4), torch.randn(8, 64, 3, 3) * 1e-6):
+        ws, sc = ops.split_conv_weight(w)
+        assert bool(torch.isfinite(ws.float()).all()) and sc > 0 and math.log2(sc) == round(math.log2(sc))
+        hi, _, lo = ws[:, :64].double(), ws[:, 64:128].double(), ws[:, 128:].double()
+        assert torch.equal(ws[:, :64], ws[:, 64:128])
+        assert float(((hi + lo) * sc - w.double()).abs().max()) <= float(w.abs().max()) * 2.0 ** -20 + 1e-30
+    # the fp32 GroupNorm kernel's shapes: 4-channel columns must lie inside one group
+    assert ops.groupnorm_nhwc_f32_ok(128, 32) and ops.groupnorm_nhwc_f32_ok(512, 32) and not ops.groupnorm_nhwc_f32_ok(64, 32)
+    assert ops.conv3x3_f32out_ok(5, 256, 1024, 384, 128) and not ops.conv3x3_f32out_ok(1, 1024, 2048, 768, 256)   # 3.2 GB operand: 32-bit offsets
+    # gates never fire for CPU tensors (the oracle / CPU-baseline copies of the VAE run plain torch)
+    blk = M.ResnetBlock2D(128, 128, None, eps=1e-6)
+    assert not M._vae_split_ok(torch.zeros(1, 128, 8, 8), blk)
+    up = M.Upsample2D(128, vae=True)
+    assert not up._split_ok(torch.zeros(1, 128, 8, 8)) and not M.Upsample2D(128)._split_ok(torch.zeros(1, 128, 8, 8))
+    x = torch.randn(2, 128, 6, 10)
+    y = up(x)                                                                                    # the library path on the CPU: unchanged semantics
+    assert tuple(y.shape) == (2, 128, 12, 20)
+    assert M._to_nchw(x.contiguous(memory_format=torch.channels_last)).is_contiguous()
+    # one hipGraph per (shape, dtype, condition, timestep shape, fresh side inputs)
+    k0 = GraphedForward._key((20, 4, 128, 128), torch.float16, None, ())
+    k1 = GraphedForward._key((20, 4, 128, 128), torch.float16, None, (), True)
+    assert k0 != k1 and k0 == GraphedForward._key((20, 4, 128, 128), torch.float16, None)
