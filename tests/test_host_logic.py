@@ -408,3 +408,32 @@ def test_round5_shape_policies_and_graph_keys():
     k0 = GraphedForward._key((20, 4, 128, 128), torch.float16, None, ())
     k1 = GraphedForward._key((20, 4, 128, 128), torch.float16, None, (), True)
     assert k0 != k1 and k0 == GraphedForward._key((20, 4, 128, 128), torch.float16, None)
+
+
+def test_precision_attribution_tool_reproduces_its_headline_on_the_reduced_width_model():
+    """tools/r5_precision_modes.py (CPU): rounding ONE class of values of the fp32 UNet to fp16 -- the reduced-width forward must show what
+    profiles/r5_precision_attribution.json shows at full width: the classes are comparable (6-7e-4 each), attention's operands are
+    negligible, all of them together land near the 1.3e-3 the MI355X measured for the fused fp16 forward, and an fp32 residual stream with
+    fp32 epilogue adds removes about a third."""
+    import importlib.util
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("r5_precision_modes", os.path.join(root, "tools", "r5_precision_modes.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    from elasticdiffusion_official_amd import models as M
+    cfg = M.SMALL_UNET_CONFIGS["sdxl"]
+    unet = M.UNet2DConditionModel(**cfg)
+    M._seeded_init(unet, 0)
+    unet = unet.eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 4, 128, 128, generator=g)
+    txt = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g)
+    kw = {"text_embeds": torch.randn(1, cfg["pooled_projection_dim"], generator=g), "time_ids": torch.zeros(1, 6)}
+    t = torch.tensor(500)
+    with torch.no_grad():
+        ref = unet(x, t, encoder_hidden_states=txt, added_cond_kwargs=kw)["sample"]
+        err = {m: tool.rel_l2(tool.Rounded(unet, tool.MODES[m], torch.float16)(x, t, encoder_hidden_states=txt, added_cond_kwargs=kw)["sample"], ref)
+               for m in ("w", "act", "attn", "fp16_model", "mixed_out32")}
+    assert 3e-4 < err["w"] < 1.2e-3 and 3e-4 < err["act"] < 1.2e-3 and err["attn"] < 1e-4, err
+    assert 8e-4 < err["fp16_model"] < 2.5e-3 and 0.5 * err["fp16_model"] < err["mixed_out32"] < 0.9 * err["fp16_model"], err
