@@ -624,7 +624,7 @@ def parity_leg(dev, dtype_name="bf16"):
             f"reference_call_pattern_{dtype_name}_vs_fp32_oracle": f(rep["ref_pattern_vs_fp32_" + dtype_name]),
             f"{dtype_name}_vs_reference_call_pattern": f(rep["batching_" + dtype_name]),
             "fp32_vs_fp32_oracle": f(rep["fp32"]),
-            "gate_vs_reference_gpu_arithmetic": {"ok": bool(ok), "detail": msg, "factor": realarch.GATE_FACTOR, "slack": realarch.GATE_SLACK,
+            "gate_vs_reference_gpu_arithmetic": {"ok": bool(ok), "detail": msg, "factor": realarch.GATE_FACTOR_BY_DTYPE.get(dtype_name, realarch.GATE_FACTOR), "slack": realarch.GATE_SLACK,
                                                  "comparator": rep.get("comparator")},
             "rng_end_state_equal": bool(rep[dtype_name + "_rng_tail_equal"] and rep["fp32_rng_tail_equal"]),
             "seconds": round(time.perf_counter() - t0, 1)}
@@ -659,11 +659,24 @@ def fp32_same_workload(make_pipe, pipe, kw, prompt, negative, wl, z16_by_seed, d
            "meets": "1e-3 rel-L2 vs the reference CPU path (fp32_model_vs_reference_cpu_path above; the fp32 loop is gated at 1e-3 "
                     "against the oracle in tests/test_real_arch_parity.py)",
            f"{dtype_name}_latent_vs_fp32_latent_rel_l2_full_width_{kw['num_inference_steps']}_steps": float(f"{rel:.4e}"),
+           # north_star's bar for the BENCHMARKED latent, decided by this run's own measurement: every compared seed
+           # of the 16-bit latent within 1e-3 rel-L2 of the fp32 loop's (which is the reference CPU path to 4e-6) -- a regression shows
+           # up as `false` in the driver's line, not in a file someone has to open
+           "meets_1e-3": bool(finite and max(rels.values()) <= 1e-3), "bar": 1e-3, "worst_rel_l2": max(rels.values()),
            "finite": finite, "graphs": p32._runner.stats(),
            "source": "measured live by this run, after the timed region", "leg_seconds": round(time.perf_counter() - t_build, 1)}
     del p32
     torch.cuda.empty_cache()
     return out
+
+
+def _gate_factor(dtype_name):
+    """the factor tests/realarch.gate_16bit really applies to this dtype (1.25 for fp16, 1.4 for bf16)"""
+    try:
+        from tests import realarch
+        return realarch.GATE_FACTOR_BY_DTYPE.get(dtype_name, realarch.GATE_FACTOR)
+    except Exception:  # noqa: BLE001
+        return {"fp16": 1.25, "bf16": 1.4}.get(dtype_name, 1.25)
 
 
 def tolerance_statement(dtype_name, fp32_live=None):
@@ -676,7 +689,7 @@ def tolerance_statement(dtype_name, fp32_live=None):
     fw = doc.get("full_width", {}).get("batches", {})
     st = {"fp32_model_vs_reference_cpu_path": {"bar": 1e-3, "measured_max": max(loop["fp32"]) if loop.get("fp32") else None},
           "benchmarked_dtype": dtype_name,
-          "bar_16bit": "per-timestep rel-L2 vs the fp32 oracle <= 1.25 x (+ 2e-4) that of the reference's call pattern in the reference's "
+          "bar_16bit": f"per-timestep rel-L2 vs the fp32 oracle <= {_gate_factor(dtype_name)} x (+ 2e-4) that of the reference's call pattern in the reference's "
                        "own GPU arithmetic, fp32 weights under torch.autocast (tests/realarch.gate_16bit; tests/test_real_arch_parity.py)",
           "where_the_16bit_error_comes_from": "profiles/r5_precision_attribution.json: of the 1.3e-3 one fp16 forward errs by at full width, "
                                               "9.2e-4 is the rounding of the MFMA operands (weights 6.7e-4, activations 6.4e-4) that "
@@ -694,7 +707,9 @@ def tolerance_statement(dtype_name, fp32_live=None):
     # kernels), measured once per round with `bench.py --dtype fp32 --steps 1` and committed
     if fp32_live is not None:
         st["fp32_unet_same_workload"] = fp32_live
+        st["meets_1e-3"] = fp32_live.get("meets_1e-3")     # true / false from THIS run's live leg; null if the leg failed
         return st
+    st["meets_1e-3"] = None                                  # no live leg in this run (--fp32-leg off / N > 1): not measured here
     f32 = load_profile_json("bench_r4_fp32_1gpu.json")
     if f32 and f32.get("dtype") == "fp32":
         st["fp32_unet_same_workload"] = {"images_per_s": f32.get("value"), "s_per_image": round(f32.get("ms_per_step", 0) / 1e3, 2),

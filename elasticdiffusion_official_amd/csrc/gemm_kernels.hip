@@ -55,6 +55,12 @@ struct BF {
   }
   static __device__ __forceinline__ float to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
   static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+  // two RNE conversions in one instruction (v_cvt_pk_bf16_f32): lo | hi << 16
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));
+  }
 };
 struct HF {
   typedef f16x8 v8;
@@ -63,6 +69,11 @@ struct HF {
   }
   static __device__ __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
   static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {      // v_cvt_pk_f16_f32 (RNE)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, h2));
+  }
 };
 
 constexpr int BM = 256;            // x rows per workgroup
@@ -90,6 +101,37 @@ __device__ __forceinline__ float gelu_as(float x) {
   const float q = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
   const float h = 0.5f * x * q;           // x Phi(x) for x < 0
   return x > 0.f ? x - h : h;             // x (1 - q/2) for x > 0
+}
+
+// The GEGLU epilogue's arithmetic, v * gelu(g), in as few VALU issues as the formula allows (round 6).  The epilogue is pure VALU time
+// during which the matrix pipe idles (PMC: MFMA busy 0.55 on GEGLU against 0.91 for the same main loop on a long-K convolution), so it
+// is paid per issue slot -- and on gfx950 a packed fp32 instruction costs two slots (SIMD-32: v_fma_f32 2 cycles, v_pk_fma_f32 4;
+// MI355X_MICROARCH.md), so what counts is the number of scalar operations per element: 18 here against 23.4 in the round-5 epilogue
+// (gelu_as + the select: 17.4 issues per element of which 6 packed).  Same values as gelu_as bit for bit: the polynomial's coefficients
+// carry the 0.5 of x Phi(x) (an exact power-of-two scaling of every Horner step),  x > 0 ? x - h : h  with h = (0.5 x) q  becomes
+// max(x, 0) - |x| (0.5 q)  (sign-symmetric products; |.| is a source modifier), and nothing is re-associated.
+// |a| * b with the absolute value as a source modifier (hipcc's SLP vectoriser otherwise packs the multiplies and pays a v_and per element
+// for the |.| a packed instruction cannot express)
+__device__ __forceinline__ float abs_mul(float a, float b) {
+  float r;
+  asm("v_mul_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max(a, 0) in ONE instruction (the builtin adds a canonicalising v_max a, a in front: a is a sum here, already canonical)
+__device__ __forceinline__ float relu1(float a) {
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ float geglu_one(float v, float g) {
+  const float z = abs_mul(g, 0.70710678118654752f);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+  p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+  const float hq = (p * t) * __builtin_amdgcn_exp2f((-1.4426950408889634f * z) * z);     // 0.5 erfc(|g| / sqrt 2)
+  return v * (relu1(g) - abs_mul(g, hq));
 }
 
 #define ED_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -346,7 +388,8 @@ template <class T, int EPI, bool CONV, bool ADD = true, bool OUT32 = false, bool
 __global__ void __launch_bounds__(512, 2)
 k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
               const uint16_t* __restrict__ row_bias, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int M,
-              int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w, int rows_per_sample, float out_scale) {
+              int K, int I, int n_blocks_n, int n_blocks, int img_h, int img_w, int rows_per_sample, float out_scale,
+              const float* __restrict__ act_absmax) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * BUF];
 
   // workgroup -> (row block, column block).  Id b runs on XCD b % 8: give every XCD a contiguous run of tile ids, and walk
@@ -511,6 +554,11 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
     const float* biasf = reinterpret_cast<const float*>(bias);
     const float* resf = reinterpret_cast<const float*>(residual);
     float* outf = reinterpret_cast<float*>(out);
+    if (act_absmax) {     // the raw-stream split scaled the activation by 2^-e (vae_kernels.hip, split_exponent): undo it, exactly
+      const int E = (int)((__builtin_bit_cast(uint32_t, *act_absmax) >> 23) & 0xffu) - 127;
+      const int e = E > 14 ? E - 14 : 0;
+      out_scale *= __builtin_bit_cast(float, (uint32_t)(127 + e) << 23);
+    }
     const bool col_v = ncol < I, col_g = ncol + gap < I;
     f32x4 b32[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
     if (biasf) {
@@ -554,9 +602,9 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          float o0 = (acc[mb][nf][2 * jj] + bv[nf][2 * jj]) * gelu_as(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
-          float o1 = (acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) * gelu_as(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
-          pk[nf * 2 + jj] = (uint32_t)T::from_f32(o0) | ((uint32_t)T::from_f32(o1) << 16);
+          const float o0 = geglu_one(acc[mb][nf][2 * jj] + bv[nf][2 * jj], acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
+          const float o1 = geglu_one(acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1], acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
+          pk[nf * 2 + jj] = T::pack2(o0, o1);
         }
       if (m < M) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
     } else {
@@ -734,9 +782,9 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          float o0 = (acc[mb][nf][2 * jj] + bv[nf][2 * jj]) * gelu_as(acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
-          float o1 = (acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1]) * gelu_as(acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
-          pk[nf * 2 + jj] = (uint32_t)T::from_f32(o0) | ((uint32_t)T::from_f32(o1) << 16);
+          const float o0 = geglu_one(acc[mb][nf][2 * jj] + bv[nf][2 * jj], acc[mb][2 + nf][2 * jj] + bg[nf][2 * jj]);
+          const float o1 = geglu_one(acc[mb][nf][2 * jj + 1] + bv[nf][2 * jj + 1], acc[mb][2 + nf][2 * jj + 1] + bg[nf][2 * jj + 1]);
+          pk[nf * 2 + jj] = T::pack2(o0, o1);
         }
       if (m < M) *reinterpret_cast<u32x4*>(out + (int64_t)m * I + ncol) = u32x4{pk[0], pk[1], pk[2], pk[3]};
     }
@@ -750,7 +798,8 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
 // C ABI (include/elastic_hip.h).  Returns 0, a hipError_t, or hipErrorInvalidValue for a shape the kernel does not take.
 template <int EPI, bool CONV, bool OUT32 = false>
 static int launch(const void* x, const void* w, const void* bias, const void* row_bias, const void* residual, void* out, int dtype,
-                  int64_t M, int K, int I, int img_h, int img_w, int rows_per_sample, void* stream, float out_scale = 1.0f) {
+                  int64_t M, int K, int I, int img_h, int img_w, int rows_per_sample, void* stream, float out_scale = 1.0f,
+                  const float* act_absmax = nullptr) {
   if (M == 0) return 0;
   const int bad = (int)hipErrorInvalidValue;
   if (M < 0 || K % BK != 0 || K < BK || I <= 0 || (EPI == 0 ? I % BN != 0 : I % 8 != 0)) return bad;
@@ -767,7 +816,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
 #define ED_LAUNCH1(TT, ADD_, TWO_)                                                                                                   \
   k_gemm_8phase<TT, EPI, CONV, ADD_, OUT32, TWO_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, \
                                                              (const uint16_t*)row_bias, (const uint16_t*)residual, (uint16_t*)out,  \
-                                                             (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1, out_scale)
+                                                             (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1, out_scale, \
+                                                             act_absmax)
 #define ED_LAUNCH(TT, ADD_)                          \
   do {                                               \
     if constexpr (CONV) {                            \
@@ -840,9 +890,10 @@ int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* 
 }
 
 int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, const float* residual, float* out, int dtype, int B, int H, int W,
-                           int Cin, int N, float out_scale, void* stream) {
-  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
-  return launch<1, true, true>(x, w, bias, nullptr, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale);
+                           int Cin, int N, float out_scale, const float* act_absmax, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || ((uintptr_t)act_absmax & 3u)) return (int)hipErrorInvalidValue;
+  return launch<1, true, true>(x, w, bias, nullptr, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale,
+                               act_absmax);
 }
 
 }  // extern "C"

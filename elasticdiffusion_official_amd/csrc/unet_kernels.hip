@@ -316,9 +316,14 @@ k_gn_split_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ ga
 }
 
 // ---- GroupNorm (+SiLU) over channels-last activations [N, HW, C] ------------------------------------
-// Two launches (round 3; three in round 2): (1) per-block partial sums per group, (2) apply, whose blocks first reduce the
-// few KB of partials of their sample themselves (in double, fixed order) instead of waiting for a separate one-block-wide
-// "finalize" launch (17.5 us mean / 113 us max per call in profiles/r2_final_bench_*: 83 ms per image for a few KB).
+// Round 6: THREE launches again -- (1) per-block partial sums per group, (2) a finalize launch of N blocks that reduces a sample's
+// partials to (mean, rstd) per group in double and fixed order, (3) apply, which reads its (at most two) groups' statistics with two
+// 8-byte loads.  Round 3 had folded (2) into every apply block's prologue to save an eager-mode launch (17.5 us each in round 2);
+// inside a hipGraph a dependent N-block kernel costs 2-3 us, and the folded prologue is what kept the chunks at 64 K elements (every
+// apply block re-read ALL of its sample's partials, so there could not be many): [20, 1280, 32, 32] ran as 400 blocks of which 160 of
+// 256 threads had a column -- 1.5 blocks per CU, 16 KiB of loads in flight per CU, 2.2 TB/s (profiles/r3_s3_probe_gn_bra.jsonl)
+// against 4.4 TB/s for the large shapes.  Now the block size follows the column count (gn_plan: no thread without a column) and the
+// chunks are sized for >= 8 blocks per CU.
 // Reads 2x, writes 1x; every access is a full 16-byte channel vector, FOUR rows in flight per thread (the round-2 loops
 // had one load outstanding per thread: 2.7-3.0 TB/s, latency-bound); the output *is* the transformer's token layout
 // (no permute copy) and the layout MIOpen's CK convolutions consume.
@@ -329,6 +334,36 @@ k_gn_split_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ ga
 // bit-reproducible statistics.
 #define GNL_MAXCOL 2  // columns per thread: C <= 8 * 256 * GNL_MAXCOL = 4096
 #define GNL_UNROLL 4  // rows in flight per thread
+
+// Launch plan of the channels-last GroupNorm (round 6), shared by the launcher and the workspace query:
+//   threads         VC = C / 8 column vectors; with VC <= 256 a block is R = 256 / VC row lanes of VC threads, rounded up to whole waves
+//                   (C = 1280: 160 columns -> 192 threads instead of 256 with 96 idle); above, 256 threads own two columns each;
+//   rows_per_block  sized for >= GNL_TARGET_BLOCKS blocks in the launch (8 per CU: ~100 KiB of loads in flight per CU), at least one
+//                   unrolled sweep (GNL_UNROLL R rows) and at most the round-3 chunk (64 K elements).
+#define GNL_TARGET_BLOCKS 2048
+struct GnPlan {
+  int threads, rows_per_block, nchunks;
+};
+static inline GnPlan gn_plan(int N, int C, int HW) {
+  GnPlan pl;
+  const int VC = C >> 3;
+  int R = 1;
+  if (VC <= GNL_THREADS) {
+    R = GNL_THREADS / VC;
+    pl.threads = ((VC * R + 63) / 64) * 64;
+  } else {
+    pl.threads = GNL_THREADS;
+  }
+  const int64_t want = ((int64_t)N * HW + GNL_TARGET_BLOCKS - 1) / GNL_TARGET_BLOCKS;   // rows per block for the target block count
+  int rpb = (int)(want < 1 ? 1 : want);
+  const int lo = GNL_UNROLL * R, hi = (65536 + C - 1) / C;
+  if (rpb < lo) rpb = lo;
+  if (rpb > hi) rpb = hi > lo ? hi : lo;
+  rpb = ((rpb + R - 1) / R) * R;            // whole row-lane sweeps
+  pl.rows_per_block = rpb;
+  pl.nchunks = (HW + rpb - 1) / rpb;
+  return pl;
+}
 
 template <typename T>
 __device__ __forceinline__ void gn_accumulate(const U16x8& v, const U16x8& kbv, bool has_kb, const U16x8& cbv, bool has_cb,
@@ -354,8 +389,9 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
   extern __shared__ float sh[];  // [lanes][VC][4]: (sum, sumsq) of the column's first / second group part
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int VC = C >> 3, cpg = C / G;
-  const int ncol = (VC + GNL_THREADS - 1) / GNL_THREADS;      // 1 or 2 columns per thread
-  const int R = ncol == 1 ? GNL_THREADS / VC : 1;            // row lanes
+  const int NT = blockDim.x;                                  // gn_plan: a multiple of 64, <= GNL_THREADS
+  const int ncol = (VC + NT - 1) / NT;                        // 1 or 2 columns per thread
+  const int R = ncol == 1 ? NT / VC : 1;                      // row lanes
   const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
   const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
   const bool active = ncol == 1 ? (int)threadIdx.x < R * VC : true;
@@ -366,7 +402,7 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
   if (active) {
 #pragma unroll
     for (int j = 0; j < GNL_MAXCOL; ++j) {
-      const int vc = my_c + j * GNL_THREADS;
+      const int vc = my_c + j * NT;
       if (j >= ncol || vc >= VC) break;
       const int c0 = vc << 3;
       const int split = (c0 / cpg + 1) * cpg - c0;  // channels [0, split) of the vector belong to its first group
@@ -394,7 +430,7 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
   __syncthreads();
   // group g: its columns in ascending order, row lanes in ascending order inside each
   float* dst = partial + ((int64_t)n * gridDim.x + chunk) * 2 * G;
-  for (int g = threadIdx.x; g < G; g += GNL_THREADS) {
+  for (int g = threadIdx.x; g < G; g += NT) {
     const int cfirst = (g * cpg) >> 3, clast = ((g + 1) * cpg - 1) >> 3;
     float s = 0.f, q = 0.f;
     for (int vc = cfirst; vc <= clast; ++vc) {
@@ -410,50 +446,64 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
   }
 }
 
-// Same thread <-> column mapping as the statistics kernel.  Prologue: the block reduces its sample's partial sums
-// [nchunks, G, 2] to mean / rstd per group in LDS -- thread (g, part) adds every GNL_PARTS-th chunk in double, then one
-// thread per group adds the GNL_PARTS parts in ascending order (deterministic) -- then gamma / beta / folded biases / the
-// (at most two) group statistics of a thread's 8 channels are loaded ONCE and it streams rows, GNL_UNROLL at a time.
+// Finalize: one block per sample reduces its partial sums [nchunks, G, 2] to (mean, rstd) per group -- thread (g, part) adds every
+// parts-th chunk in double, then one thread per group adds the parts in ascending order (deterministic; the arithmetic of the round-3
+// apply prologue, now run once per sample instead of once per apply block).
 #define GNL_MAXG 256
+__global__ void __launch_bounds__(GNL_THREADS)
+k_gn_nhwc_finalize(const float* __restrict__ partial, float* __restrict__ stats_out, int G, int nchunks, double count, float eps) {
+  __shared__ double red[2 * GNL_THREADS];
+  const int n = blockIdx.x;
+  const int parts = GNL_THREADS / G > 0 ? GNL_THREADS / G : 1;  // G <= 256
+  const int g = threadIdx.x % G, part = threadIdx.x / G;
+  double s = 0.0, q = 0.0;
+  if (part < parts) {
+    const float* p = partial + (int64_t)n * nchunks * 2 * G + 2 * g;
+    int c = part;
+    for (; c + 3 * parts < nchunks; c += 4 * parts) {          // four independent 8-byte loads in flight
+      const float2 v0 = *reinterpret_cast<const float2*>(p + (int64_t)c * 2 * G);
+      const float2 v1 = *reinterpret_cast<const float2*>(p + (int64_t)(c + parts) * 2 * G);
+      const float2 v2 = *reinterpret_cast<const float2*>(p + (int64_t)(c + 2 * parts) * 2 * G);
+      const float2 v3 = *reinterpret_cast<const float2*>(p + (int64_t)(c + 3 * parts) * 2 * G);
+      s += (double)v0.x, q += (double)v0.y;
+      s += (double)v1.x, q += (double)v1.y;
+      s += (double)v2.x, q += (double)v2.y;
+      s += (double)v3.x, q += (double)v3.y;
+    }
+    for (; c < nchunks; c += parts) {
+      s += (double)p[(int64_t)c * 2 * G];
+      q += (double)p[(int64_t)c * 2 * G + 1];
+    }
+  }
+  red[2 * threadIdx.x] = s, red[2 * threadIdx.x + 1] = q;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    double ss = 0.0, qq = 0.0;
+    for (int k = 0; k < parts; ++k) {
+      ss += red[2 * (k * G + threadIdx.x)];
+      qq += red[2 * (k * G + threadIdx.x) + 1];
+    }
+    const double mean = ss / count;
+    double var = qq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats_out[((int64_t)n * G + threadIdx.x) * 2] = (float)mean;
+    stats_out[((int64_t)n * G + threadIdx.x) * 2 + 1] = rsqrtf((float)var + eps);
+  }
+}
+
+// Same thread <-> column mapping as the statistics kernel: gamma / beta / folded biases / the (at most two) group statistics of a
+// thread's 8 channels are loaded ONCE and it streams rows, GNL_UNROLL at a time.
 template <typename T, bool ACT>
 __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
-                const float* __restrict__ partial, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block,
-                double count, float eps) {
-  __shared__ double red[2 * GNL_THREADS];
-  __shared__ float stats[2 * GNL_MAXG];
-  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-  {
-    const int parts = GNL_THREADS / G > 0 ? GNL_THREADS / G : 1;  // G <= 256
-    const int g = threadIdx.x % G, part = threadIdx.x / G;
-    double s = 0.0, q = 0.0;
-    if (part < parts) {
-      const float* p = partial + (int64_t)n * nchunks * 2 * G + 2 * g;
-      for (int c = part; c < nchunks; c += parts) {
-        s += (double)p[(int64_t)c * 2 * G];
-        q += (double)p[(int64_t)c * 2 * G + 1];
-      }
-    }
-    red[2 * threadIdx.x] = s, red[2 * threadIdx.x + 1] = q;
-    __syncthreads();
-    if ((int)threadIdx.x < G) {
-      double ss = 0.0, qq = 0.0;
-      for (int k = 0; k < parts; ++k) {
-        ss += red[2 * (k * G + threadIdx.x)];
-        qq += red[2 * (k * G + threadIdx.x) + 1];
-      }
-      const double mean = ss / count;
-      double var = qq / count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      stats[2 * threadIdx.x] = (float)mean;
-      stats[2 * threadIdx.x + 1] = rsqrtf((float)var + eps);
-    }
-    __syncthreads();
-  }
+                const float* __restrict__ stats_all, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block) {
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const float* stats = stats_all + (int64_t)n * G * 2;
   const int VC = C >> 3, cpg = C / G;
-  const int ncol = (VC + GNL_THREADS - 1) / GNL_THREADS;
-  const int R = ncol == 1 ? GNL_THREADS / VC : 1;
+  const int NT = blockDim.x;
+  const int ncol = (VC + NT - 1) / NT;
+  const int R = ncol == 1 ? NT / VC : 1;
   const int my_r = ncol == 1 ? threadIdx.x / VC : 0;
   const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
   if (ncol == 1 && (int)threadIdx.x >= R * VC) return;
@@ -463,7 +513,7 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
   uint16_t* ob = out + (int64_t)n * HW * C;
 #pragma unroll
   for (int j = 0; j < GNL_MAXCOL; ++j) {
-    const int vc = my_c + j * GNL_THREADS;
+    const int vc = my_c + j * NT;
     if (j >= ncol || vc >= VC) break;
     const int c0 = vc << 3;
     const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;  // C/G >= 8: a vector touches at most two groups
@@ -1022,27 +1072,27 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  // ~64 K elements per partial block keeps >= 256 blocks in flight for every UNet shape at batch >= 3
-  int rows_per_block = (65536 + C - 1) / C;
-  if (rows_per_block < 1) rows_per_block = 1;
-  int nchunks = (HW + rows_per_block - 1) / rows_per_block;
+  const GnPlan pl = gn_plan(N, C, HW);
   float* partial = workspace;                                // [N, nchunks, G, 2]
-  dim3 grid1(nchunks, N);
+  float* stats = workspace + (int64_t)N * pl.nchunks * G * 2;  // [N, G, 2]: (mean, rstd), written by the finalize launch
+  dim3 grid1(pl.nchunks, N);
   const int VC_ = C / 8;
-  size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= GNL_THREADS ? GNL_THREADS / VC_ : 1);
+  size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= pl.threads ? pl.threads / VC_ : 1);
+  const int rows_per_block = pl.rows_per_block;
 #define GNL_RUN(T)                                                                                                     \
-  k_gn_nhwc_partial<T><<<grid1, GNL_THREADS, lds, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                \
-                                                       (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
+  k_gn_nhwc_partial<T><<<grid1, pl.threads, lds, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                 \
+                                                      (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
+  k_gn_nhwc_finalize<<<N, GNL_THREADS, 0, s>>>(partial, stats, G, pl.nchunks, (double)HW * (C / G), eps);             \
   if (act_silu)                                                                                                        \
-    k_gn_nhwc_apply<T, true><<<grid1, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
-                                                          (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
-                                                          (const uint16_t*)chan_bias, partial, (uint16_t*)out, C, HW,  \
-                                                          G, rows_per_block, (double)HW * (C / G), eps);               \
+    k_gn_nhwc_apply<T, true><<<grid1, pl.threads, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                  \
+                                                         (const uint16_t*)beta, (const uint16_t*)conv_bias,            \
+                                                         (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW,     \
+                                                         G, rows_per_block);                                           \
   else                                                                                                                 \
-    k_gn_nhwc_apply<T, false><<<grid1, GNL_THREADS, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                \
-                                                           (const uint16_t*)beta, (const uint16_t*)conv_bias,          \
-                                                           (const uint16_t*)chan_bias, partial, (uint16_t*)out, C, HW, \
-                                                           G, rows_per_block, (double)HW * (C / G), eps);
+    k_gn_nhwc_apply<T, false><<<grid1, pl.threads, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
+                                                          (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
+                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW,    \
+                                                          G, rows_per_block);
   if (dtype == ED_BF16) {
     GNL_RUN(BF16)
   } else if (dtype == ED_F16) {
@@ -1186,10 +1236,9 @@ int ed_softmax_rows(void* x, int64_t rows, int64_t cols, float scale, void* stre
 }
 
 int64_t ed_groupnorm_nhwc_workspace(int N, int C, int HW, int G) {
-  int rows_per_block = (65536 + C - 1) / C;
-  if (rows_per_block < 1) rows_per_block = 1;
-  int nchunks = (HW + rows_per_block - 1) / rows_per_block;
-  return ((int64_t)N * nchunks * G * 2 + (int64_t)N * G * 2) * (int64_t)sizeof(float);
+  if (N <= 0 || C <= 0 || HW <= 0 || G <= 0) return 0;
+  const GnPlan pl = gn_plan(N, C, HW);
+  return ((int64_t)N * pl.nchunks * G * 2 + (int64_t)N * G * 2) * (int64_t)sizeof(float);
 }
 
 }  // extern "C"

@@ -28,6 +28,14 @@ namespace {
 #define GV_MAXG 256
 
 __device__ __forceinline__ float silu32(float x) { return x / (1.0f + expf(-x)); }
+// fp16(clamp(v, +-65504)): identical to (_Float16)v inside fp16's range (NaN stays NaN: both comparisons are false)
+__device__ __forceinline__ _Float16 sat16(float v) { return (_Float16)(v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v)); }
+// the per-tensor power of two of the raw-stream split: e = max(0, exponent(absmax) - 14), so that |2^-e v| < 2^15 for every |v| <= absmax
+// (gemm_kernels.hip holds the same three lines for the convolution's 2^e)
+__device__ __forceinline__ int split_exponent(float absmax) {
+  const int E = (int)((__builtin_bit_cast(uint32_t, absmax) >> 23) & 0xffu) - 127;
+  return E > 14 ? E - 14 : 0;
+}
 
 // ---- statistics: every thread owns one 4-channel column (cpg % 4 == 0: the column lies inside ONE group) and walks rows ----------
 // x [N, HW, C] fp32 (channels-last memory of a [N, C, H, W] tensor); partial [N, nchunks, G, 2] (sum, sum of squares), fixed summation
@@ -151,9 +159,9 @@ k_gn32_nhwc_apply(const float* __restrict__ x, const float* __restrict__ gamma, 
     auto store = [&](int64_t row, const float4& y) {
       if (SPLIT) {
         uint16_t* ob = reinterpret_cast<uint16_t*>(out) + ((int64_t)n * HW + row) * (3 * (int64_t)C) + c0;
-        const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
-        const _Float16 l0 = (_Float16)(y.x - (float)h0), l1 = (_Float16)(y.y - (float)h1), l2 = (_Float16)(y.z - (float)h2),
-                       l3 = (_Float16)(y.w - (float)h3);
+        // saturating (round 6): a value beyond fp16's range gives a finite clamped operand, never hi = inf, lo = -inf
+        const _Float16 h0 = sat16(y.x), h1 = sat16(y.y), h2 = sat16(y.z), h3 = sat16(y.w);
+        const _Float16 l0 = sat16(y.x - (float)h0), l1 = sat16(y.y - (float)h1), l2 = sat16(y.z - (float)h2), l3 = sat16(y.w - (float)h3);
         uint2 hi, lo;
         hi.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
         hi.y = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
@@ -182,27 +190,28 @@ k_gn32_nhwc_apply(const float* __restrict__ x, const float* __restrict__ gamma, 
 
 // ---- split of a raw fp32 channels-last activation (no normalisation in front of it: the decoder's upsampler convolutions) -----------
 // x fp32 [N, H, W, C] -> out fp16 [N, U H, U W, 3 C] = [hi | lo | hi], U = 1 or 2 (nearest-neighbour 2x upsampling folded into the write:
-// every input pixel lands on its U x U output pixels).  The stream is not bounded by an affine map, so hi SATURATES at fp16's largest
-// finite value instead of overflowing: hi = fp16(clamp(v, +-65504)), lo = fp16(v - hi) -- hi + lo then represents |v| up to 1.3e5 and
-// degrades gracefully above 65504 (lo alone carries the excess with 11 bits) instead of producing inf - inf.
+// every input pixel lands on its U x U output pixels).  The stream is not bounded by an affine map (the real SDXL decoder stream leaves
+// fp16's range), so the tensor is scaled by 2^-e, e from its absolute maximum (k_absmax32 below; exact), before the split, and the
+// convolution multiplies by 2^e: exact over the whole fp32 range (round 6; round 5 clamped hi only: 11 bits in (65504, 1.3e5], inf - inf
+// beyond).  Without an absmax (NULL) hi and lo both saturate: finite everywhere, exact up to 65504.
 template <int U>
 __global__ void __launch_bounds__(256)
-k_split32_nhwc(const float* __restrict__ x, uint16_t* __restrict__ out, int C, int H, int W, int64_t n_vec) {
+k_split32_nhwc(const float* __restrict__ x, uint16_t* __restrict__ out, int C, int H, int W, int64_t n_vec, const float* __restrict__ absmax) {
   const int VC = C >> 2;
+  const float sc = absmax ? __builtin_bit_cast(float, (uint32_t)(127 - split_exponent(*absmax)) << 23) : 1.0f;   // 2^-e
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = i / VC;
     const int c0 = (int)(i - pix * VC) << 2;
     const float4 v = *reinterpret_cast<const float4*>(x + pix * C + c0);
-    const float f[4] = {v.x, v.y, v.z, v.w};
+    const float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
     uint32_t hw[2], lw[2];
 #pragma unroll
     for (int e = 0; e < 4; e += 2) {
       uint16_t hb[2], lb[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float c = fminf(fmaxf(f[e + j], -65504.f), 65504.f);
-        const _Float16 h = (_Float16)c;
-        const _Float16 l = (_Float16)(f[e + j] - (float)h);
+        const _Float16 h = sat16(f[e + j]);
+        const _Float16 l = sat16(f[e + j] - (float)h);
         hb[j] = __builtin_bit_cast(uint16_t, h), lb[j] = __builtin_bit_cast(uint16_t, l);
       }
       hw[e >> 1] = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
@@ -221,6 +230,22 @@ k_split32_nhwc(const float* __restrict__ x, uint16_t* __restrict__ out, int C, i
         *reinterpret_cast<uint2*>(ob + 2 * C) = hi;
       }
   }
+}
+
+// ---- max |x| of an fp32 tensor as a bit pattern (non-negative floats order like unsigned integers; NaN patterns sort above Inf) ------
+__global__ void __launch_bounds__(256)
+k_absmax32(const float* __restrict__ x, uint32_t* __restrict__ out, int64_t n) {
+  uint32_t m = 0;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + 4 * i);
+    const uint32_t a = max(v.x & 0x7fffffffu, v.y & 0x7fffffffu), b = max(v.z & 0x7fffffffu, v.w & 0x7fffffffu);
+    m = max(m, max(a, b));
+  }
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - 4 * n4) m = max(m, __builtin_bit_cast(uint32_t, x[4 * n4 + threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 inline int done() { return (int)hipGetLastError(); }
@@ -270,16 +295,30 @@ int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, vo
   return done();
 }
 
-int ed_split_f32_nhwc(const void* x, void* out, int N, int C, int H, int W, int upsample2x, void* stream) {
+int ed_absmax_f32(const void* x, int64_t n, float* out, void* stream) {
+  if (n < 0 || !out || ((uintptr_t)x & 15u) || ((uintptr_t)out & 3u)) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  if (n == 0) return 0;
+  int64_t blocks = ((n >> 2) + 256 * 8 - 1) / (256 * 8);      // 8 16-byte loads per thread
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  k_absmax32<<<(unsigned)blocks, 256, 0, s>>>((const float*)x, reinterpret_cast<uint32_t*>(out), n);
+  return done();
+}
+
+int ed_split_f32_nhwc(const void* x, void* out, int N, int C, int H, int W, int upsample2x, const float* absmax, void* stream) {
   if (N == 0) return 0;
-  if (N < 0 || C <= 0 || C % 4 != 0 || H <= 0 || W <= 0 || (((uintptr_t)x | (uintptr_t)out) & 15u) || ((3 * C * 2) % 8) != 0)
+  if (N < 0 || C <= 0 || C % 4 != 0 || H <= 0 || W <= 0 || (((uintptr_t)x | (uintptr_t)out) & 15u) || ((3 * C * 2) % 8) != 0 ||
+      ((uintptr_t)absmax & 3u))
     return (int)hipErrorInvalidValue;
   const int64_t n_vec = (int64_t)N * H * W * (C / 4);
   int64_t blocks = (n_vec + 255) / 256;
   if (blocks > 65536 * 16) blocks = 65536 * 16;
   hipStream_t s = (hipStream_t)stream;
-  if (upsample2x) k_split32_nhwc<2><<<(unsigned)blocks, 256, 0, s>>>((const float*)x, (uint16_t*)out, C, H, W, n_vec);
-  else k_split32_nhwc<1><<<(unsigned)blocks, 256, 0, s>>>((const float*)x, (uint16_t*)out, C, H, W, n_vec);
+  if (upsample2x) k_split32_nhwc<2><<<(unsigned)blocks, 256, 0, s>>>((const float*)x, (uint16_t*)out, C, H, W, n_vec, absmax);
+  else k_split32_nhwc<1><<<(unsigned)blocks, 256, 0, s>>>((const float*)x, (uint16_t*)out, C, H, W, n_vec, absmax);
   return done();
 }
 

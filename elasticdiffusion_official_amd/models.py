@@ -178,13 +178,36 @@ def _vae_split_ok(x, blk):
 def _split_weight(conv):
     """(split fp16 weight, 2^-k) of a Conv2d for ops.conv3x3_f32out, rebuilt when the weight changes"""
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device))
+    # id(w): a fresh Parameter the caching allocator placed at the freed address (same data_ptr, version 0) must not hit (ADVICE r5)
+    key = (id(w), w.data_ptr(), w._version, str(w.device))
     hit = conv.__dict__.get("_split_w")
     if hit is None or hit[0] != key:
         from . import ops
         hit = (key,) + ops.split_conv_weight(w)
         conv.__dict__["_split_w"] = hit
     return hit[1], hit[2]
+
+
+def prepare_vae_split(vae):
+    """Build the split fp16 weights of every convolution of an fp32 VAE that can take the split-operand path NOW (model load), so that
+    the one host synchronisation of ``ops.split_conv_weight`` (the weight's absolute maximum) never falls into a forward -- or a stream
+    capture -- later.  A no-op for a CPU / 16-bit VAE or with the switch off; a weight that changes afterwards is re-split
+    on its next use (``_split_weight``'s key)."""
+    if not (VAE_SPLIT_CONV and FUSED_KERNELS):
+        return 0
+    n = 0
+    for m in vae.modules():
+        convs = ()
+        if isinstance(m, ResnetBlock2D) and m.time_emb_proj is None:
+            convs = (m.conv1, m.conv2)
+        elif isinstance(m, Upsample2D) and m.vae:
+            convs = (m.conv,)
+        for c in convs:
+            w = c.weight
+            if w.is_cuda and w.dtype == torch.float32 and w.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and tuple(w.shape[2:]) == (3, 3):
+                _split_weight(c)
+                n += 1
+    return n
 
 
 def layer_norm(norm, x):
@@ -511,15 +534,19 @@ class Upsample2D(nn.Module):
     def forward(self, x):
         if x.dtype == torch.float32:
             if self._split_ok(x):
-                # the VAE decoder's upsampler on the MFMA pipe (VAE_SPLIT_CONV): the raw stream is split with a saturating hi and upsampled
-                # in one pass, the convolution is the same split-operand main loop as the ResnetBlocks'; channels-last in and out
+                # the VAE decoder's upsampler on the MFMA pipe (VAE_SPLIT_CONV): the raw stream is split (scaled by a per-tensor power of
+                # two taken from its absolute maximum on the device: the real decoder stream leaves fp16's range) and upsampled in one pass, the convolution is the same split-operand main loop as the ResnetBlocks'; channels-last in and out
                 from . import ops
                 w, sc = _split_weight(self.conv)
                 cl = torch.channels_last
                 x = x.contiguous(memory_format=cl)
                 B, C, H, W = x.shape
                 nb = max(1, (2 ** 31 - 16) // (4 * H * W * 3 * C * 2))
-                outs = [ops.conv3x3_f32out(ops.split_f32(x[i:i + nb], upsample2x=True), w, self.conv.bias, None, sc) for i in range(0, B, nb)]
+                outs = []
+                for i in range(0, B, nb):
+                    xs = x[i:i + nb]
+                    am = ops.absmax_f32(xs)     # per-slice power-of-two scale: the split is exact over the whole fp32 range
+                    outs.append(ops.conv3x3_f32out(ops.split_f32(xs, upsample2x=True, absmax=am), w, self.conv.bias, None, sc, act_absmax=am))
                 return outs[0] if len(outs) == 1 else torch.cat(outs).contiguous(memory_format=cl)
             x = _to_nchw(x)  # NCHW for MIOpen's fp32 solvers (the UNet's 16-bit activations stay channels-last)
         up = F.interpolate(x, scale_factor=2.0, mode="nearest")

@@ -584,12 +584,31 @@ def groupnorm_nhwc_f32(x, gamma, beta, groups, eps, silu=False, split=False):
     return out
 
 
-def split_f32(x, upsample2x=False):
+def absmax_f32(x):
+    """max |x| of a contiguous-in-memory fp32 tensor as a 1-element device tensor (ed_absmax_f32): the per-tensor figure the raw-stream
+    split scales by.  No host synchronisation."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+        _reject("absmax_f32: x must be an fp32 tensor on the MI355X; no CPU fallback")
+    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
+        _reject("absmax_f32: x must be dense (contiguous or channels_last)")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    TIMER.note_work("ed_absmax_f32", nbytes=x.numel() * 4.0)
+    _LAUNCH["device"] = x.device
+    _call("ed_absmax_f32", x.data_ptr(), x.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def split_f32(x, upsample2x=False, absmax=None):
     """x [N,C,H,W] fp32 in channels_last memory -> the fp16 channels_last [N,3C,UH,UW] = [hi | lo | hi] operand of ``conv3x3_f32out`` for a
-    raw (un-normalised) activation, U = 2 with ``upsample2x`` (nearest-neighbour upsampling folded in).  hi saturates at fp16's largest
-    finite value.  See ed_split_f32_nhwc."""
+    raw (un-normalised) activation, U = 2 with ``upsample2x`` (nearest-neighbour upsampling folded in).  ``absmax`` (``absmax_f32(x)``, a
+    1-element device tensor): the activation is scaled by 2^-e, e = max(0, exponent(absmax) - 14), before the split -- exact over the
+    whole fp32 range; hand the SAME tensor to ``conv3x3_f32out(act_absmax=)``, which multiplies by 2^e.  Without it hi and lo saturate at
+    fp16's largest finite value (exact up to 65504).  See ed_split_f32_nhwc."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32):
         _reject("split_f32: x must be an fp32 [N,C,H,W] tensor on the MI355X; no CPU fallback")
+    if absmax is not None and not (isinstance(absmax, torch.Tensor) and absmax.device == x.device and absmax.dtype == torch.float32
+                                   and absmax.numel() == 1):
+        _reject("split_f32: absmax must be a 1-element fp32 tensor on x's device")
     N, C, H, W = x.shape
     cl = torch.channels_last
     if not x.is_contiguous(memory_format=cl) or C % 4:
@@ -598,7 +617,8 @@ def split_f32(x, upsample2x=False):
     out = torch.empty((N, 3 * C, u * H, u * W), dtype=torch.float16, device=x.device, memory_format=cl)
     TIMER.note_work("ed_split_f32_nhwc", nbytes=x.numel() * (4.0 + 6.0 * u * u))
     _LAUNCH["device"] = x.device
-    _call("ed_split_f32_nhwc", x.data_ptr(), out.data_ptr(), N, C, H, W, int(bool(upsample2x)), _stream())
+    _call("ed_split_f32_nhwc", x.data_ptr(), out.data_ptr(), N, C, H, W, int(bool(upsample2x)),
+          None if absmax is None else absmax.data_ptr(), _stream())
     return out
 
 
@@ -620,10 +640,11 @@ def conv3x3_f32out_ok(B, H, W, Cin3, N):
     return Cin3 % 64 == 0 and N % 8 == 0 and M * Cin3 * 2 < 2 ** 31 - 16 and N * 9 * Cin3 * 2 < 2 ** 31 - 16 and M < 2 ** 31
 
 
-def conv3x3_f32out(a, w, bias=None, residual=None, out_scale=1.0):
+def conv3x3_f32out(a, w, bias=None, residual=None, out_scale=1.0, act_absmax=None):
     """a [B,Cin',H,W] fp16 and w [N,Cin',3,3] fp16 in channels_last memory (split operands: Cin' = 3 Cin, ``groupnorm_nhwc_f32(split=True)``
     / ``split_conv_weight``) -> out_scale * conv2d(a, w, stride 1, padding 1) + bias + residual as fp32 channels_last [B,N,H,W]; bias fp32
-    [N], residual fp32 channels_last.  See ed_conv3x3_nhwc_f32out."""
+    [N], residual fp32 channels_last.  ``act_absmax``: the tensor ``split_f32`` scaled ``a`` by (the result is multiplied by 2^e).
+    See ed_conv3x3_nhwc_f32out."""
     if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dim() == 4 and a.dtype == torch.float16):
         _reject("conv3x3_f32out: a must be an fp16 [B,C,H,W] tensor on the MI355X; no CPU fallback")
     B, C3, H, W = a.shape
@@ -639,7 +660,8 @@ def conv3x3_f32out(a, w, bias=None, residual=None, out_scale=1.0):
     TIMER.note_work("ed_conv3x3_nhwc_f32out", flops=2.0 * B * H * W * 9 * C3 * N,
                     nbytes=2.0 * (B * H * W * C3 + 9 * C3 * N) + 4.0 * B * H * W * N * (2 if residual is not None else 1))
     _call("ed_conv3x3_nhwc_f32out", a.data_ptr(), w.data_ptr(), _opt(bias, torch.float32, "bias"),
-          None if residual is None else residual.data_ptr(), out.data_ptr(), _DTYPE[torch.float16], B, H, W, C3, N, float(out_scale), _stream_of(a))
+          None if residual is None else residual.data_ptr(), out.data_ptr(), _DTYPE[torch.float16], B, H, W, C3, N, float(out_scale),
+          None if act_absmax is None else act_absmax.data_ptr(), _stream_of(a))
     return out
 
 

@@ -196,6 +196,9 @@ class ElasticDiffusion(nn.Module):
             vae = vae if vae is not None else built_vae
         self.unet = self._model_layout(unet.to(device))
         self.vae = vae.to(device)
+        if isinstance(self.vae, torch.nn.Module) and self.device.type == "cuda":
+            from .models import prepare_vae_split
+            prepare_vae_split(self.vae)     # split fp16 weights of the fp32 VAE's MFMA convolutions, built at load time
         self.controlnet = self._model_layout(controlnet.to(device)) if controlnet is not None else None
         if scheduler is None:
             scheduler = DDIMSchedule.from_config_dir(weights) if weights else DDIMSchedule()  # ED:153

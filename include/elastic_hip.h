@@ -372,23 +372,32 @@ int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* 
  * ed_groupnorm_nhwc_f32 -- GroupNorm [+ SiLU] of an fp32 channels-last activation x [N, HW, C] (statistics in fp32 partial sums
  *   combined in double, fixed order):  split16 = 0: out fp32 [N, HW, C];  split16 = 1: out fp16 [N, HW, 3 C] = [hi | lo | hi], the
  *   A operand of ed_conv3x3_nhwc_f32out (after GroupNorm + SiLU the values are bounded by the affine parameters: fp16's range is
- *   safe).  (C / G) % 4 == 0, G <= 256; workspace: ed_groupnorm_nhwc_f32_workspace bytes; pointers 16-byte aligned.
+ *   safe; hi and lo nevertheless SATURATE at +-65504 -- a value beyond the range gives a finite, clamped operand, never inf - inf).  (C / G) % 4 == 0, G <= 256; workspace: ed_groupnorm_nhwc_f32_workspace bytes; pointers 16-byte aligned.
  * ed_conv3x3_nhwc_f32out -- ed_conv3x3_nhwc's main loop with an fp32 epilogue:
  *   out[b,y,x,n] = out_scale * sum_{dy,dx,c} x[b,y+dy,x+dx,c] w[n,dy,dx,c] + bias[n] + residual[b,y,x,n]      (no 16-bit rounding)
  *   x fp16 [B,H,W,Cin'] and w fp16 [N,3,3,Cin'] (Cin' = 3 Cin for split operands; any Cin' % 64 == 0 works), bias fp32 [N] or NULL,
  *   residual fp32 [B,H,W,N] or NULL, out fp32 [B,H,W,N]; dtype must be ED_F16; out_scale: a power of two that undoes the
- *   pre-scaling of the split weights (which keeps wl out of fp16's subnormal range).  N % 8 == 0, 32-bit operand offsets as above.
+ *   pre-scaling of the split weights (which keeps wl out of fp16's subnormal range); act_absmax: NULL, or the device float that
+ *   ed_split_f32_nhwc scaled the activation by (the result is multiplied by 2^e, see there).  N % 8 == 0, 32-bit operand offsets as above.
  * ed_split_f32_nhwc -- the same (hi, lo) split for a RAW fp32 channels-last activation x [N, H, W, C] (the VAE decoder's upsampler
  *   convolutions, whose input is the un-normalised stream): out fp16 [N, U H, U W, 3 C] = [hi | lo | hi], U = 2 with upsample2x (nearest-
- *   neighbour upsampling folded into the write), else 1.  hi saturates at +-65504 instead of overflowing (hi + lo then carries |v| up to
- *   1.3e5, with lo's 11 bits above 65504).  C % 4 == 0; pointers 16-byte aligned.
+ *   neighbour upsampling folded into the write), else 1.  The raw stream is NOT bounded (the real SDXL decoder stream leaves fp16's
+ *   range -- it is why that VAE produces NaNs in fp16), so the split is made exact over the whole fp32 range by a per-tensor power of
+ *   two (round 6):  absmax -> e = max(0, exponent(absmax) - 14);  the kernel splits 2^-e v (|2^-e v| < 2^15: hi never
+ *   saturates) and ed_conv3x3_nhwc_f32out multiplies its result by 2^e (its `act_absmax` argument: the SAME device float).  Scaling
+ *   by a power of two is exact, so hi + lo = v to 2^-22 |v| as in the bounded case.  absmax = NULL: no scaling; hi AND lo then saturate
+ *   at +-65504 (finite, never inf - inf; exact up to |v| = 65504, 11 bits up to 1.3e5).  C % 4 == 0; pointers 16-byte aligned.
+ * ed_absmax_f32 -- out[0] = max |x[i]| over n fp32 values (bit pattern maximum: a NaN input yields a NaN, an Inf an Inf), the
+ *   per-tensor figure above.  One device float, written by this call in stream order (memset + atomic max of the non-negative bit
+ *   patterns: order-independent, bit-reproducible).
  */
-int ed_split_f32_nhwc(const void* x, void* out, int N, int C, int H, int W, int upsample2x, void* stream);
+int ed_absmax_f32(const void* x, int64_t n, float* out, void* stream);
+int ed_split_f32_nhwc(const void* x, void* out, int N, int C, int H, int W, int upsample2x, const float* absmax, void* stream);
 int64_t ed_groupnorm_nhwc_f32_workspace(int N, int C, int HW, int G);
 int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int N, int C, int HW, int G,
                           float eps, int act_silu, int split16, void* stream);
 int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, const float* residual, float* out, int dtype, int B, int H, int W,
-                           int Cin, int N, float out_scale, void* stream);
+                           int Cin, int N, float out_scale, const float* act_absmax, void* stream);
 
 #ifdef __cplusplus
 }

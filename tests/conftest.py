@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# The builder / judge container has 8 cores and no GPU: cap the main process's intra-op threads there so that the suite's dense CPU legs
+# (oracle vs reference, precision attribution) and the background replay pool (tests/replays.py) do not oversubscribe the box with
+# spinning OpenMP workers -- the one way this suite was ever seen to take 20 minutes instead of 4.  A GPU box (many cores,
+# /dev/kfd present) keeps torch's default: its oracle legs want every core.
+if not os.path.exists("/dev/kfd"):
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(4, os.cpu_count() or 1))))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -16,3 +23,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        from tests import replays
+        replays.kill_all()      # -x stopped the run early: no replay subprocess may outlive it
+    except Exception:  # noqa: BLE001
+        pass

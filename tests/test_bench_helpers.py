@@ -54,7 +54,9 @@ def test_workloads_cover_every_baseline_config_and_controlnet_flops():
 def test_tolerance_statement_shape():
     st = bench.tolerance_statement("bf16")
     assert st["fp32_model_vs_reference_cpu_path"]["bar"] == 1e-3 and st["benchmarked_dtype"] == "bf16"
-    assert "1.25 x" in st["bar_16bit"] and st["evidence"] == "profiles/r3_precision.json"
+    assert "1.4 x" in st["bar_16bit"] and st["evidence"] == "profiles/r3_precision.json"     # bf16's own factor
+    assert "1.25 x" in bench.tolerance_statement("fp16")["bar_16bit"]
+    assert st["meets_1e-3"] is None                                                          # no live leg: not measured, not claimed
 
 
 def test_tolerance_statement_prefers_the_live_fp32_leg_and_flags_a_file_fallback():
@@ -62,6 +64,9 @@ def test_tolerance_statement_prefers_the_live_fp32_leg_and_flags_a_file_fallback
             "source": "measured live by this run, after the timed region"}
     st = bench.tolerance_statement("fp16", live)
     assert st["fp32_unet_same_workload"] is live and "where_the_16bit_error_comes_from" in st
+    assert st["meets_1e-3"] is None          # a leg that did not report the flag (an error record) claims nothing
+    assert bench.tolerance_statement("fp16", dict(live, **{"meets_1e-3": True}))["meets_1e-3"] is True
+    assert bench.tolerance_statement("fp16", dict(live, **{"meets_1e-3": False}))["meets_1e-3"] is False
     st = bench.tolerance_statement("fp16")   # no live leg (N > 1, --fp32-leg off): the committed figure, labelled with its file
     assert st["fp32_unet_same_workload"]["source"].startswith("profiles/")
 

@@ -9,17 +9,15 @@ import sys
 
 import pytest
 
-from tests import procs
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_gemm_kernel_replay_is_exact_and_catches_broken_schedules():
-    run = lambda *a: procs.run([sys.executable, os.path.join(ROOT, "tools", "emulate_gemm_kernel.py"), "--quick", *a], 600, cwd=ROOT)
-    ok = run()
+    from tests import replays     # one background pool for every replay of the suite (tests/replays.py)
+    ok = replays.result("gemm_quick")
     assert ok.returncode == 0 and "WRONG" not in ok.stdout, ok.stdout + ok.stderr
     for brk in ("war", "raw", "lgkm", "early"):   # early: the first K tile's counted waits one DMA pair too weak
-        out = run("--break", brk)
+        out = replays.result("gemm_quick_" + brk)
         assert out.returncode == 0 and "caught the deliberately broken schedule" in out.stdout, out.stdout + out.stderr
 
 

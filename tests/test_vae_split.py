@@ -197,3 +197,102 @@ def test_vae_upsampler_split_vs_library():
     assert got.shape == lib.shape and got.is_contiguous(memory_format=torch.channels_last)
     e, elib = _rel(got, want), _rel(lib, want)
     assert e <= max(2.0 * elib, 6e-7), (e, elib)
+
+
+# ---- round 6: the raw-stream split is exact over the WHOLE fp32 range ----------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("peak", [3.0e4, 7.0e4, 1.4e5, 2.5e6, 3.0e9, 1.0e30])
+def test_split_f32_with_absmax_scale_is_exact_beyond_fp16_range(peak):
+    """|v| far beyond 1.3e5 (where round 5's saturating hi ran out of bits, and beyond 131 008 produced inf - inf): with the per-tensor
+    power-of-two scale hi + lo = 2^-e v to 2^-22 for every element, nothing saturates, and the convolution's 2^e brings the result back:
+    finite and as accurate as the library's fp32 convolution against fp64."""
+    import math
+    from elasticdiffusion_official_amd import ops
+    dev = "cuda:0"
+    cl = torch.channels_last
+    g = torch.Generator(device="cpu").manual_seed(int(math.log2(peak)))
+    N, C, H, W, Nout = 2, 128, 10, 14, 128
+    x = torch.randn(N, C, H, W, generator=g) * (peak / 6)
+    x[0, 3, 2, 5], x[1, 7, 9, 13] = peak, -peak * 0.75
+    x = x.to(dev).contiguous(memory_format=cl)
+    am = ops.absmax_f32(x)
+    assert float(am) == float(x.abs().max()) and torch.equal(am, ops.absmax_f32(x))
+    e = max(0, math.frexp(float(am))[1] - 1 - 14)
+    s = ops.split_f32(x, upsample2x=True, absmax=am)
+    assert bool(torch.isfinite(s.float()).all())
+    hi, lo = s[:, :C].double(), s[:, C:2 * C].double()
+    want = F.interpolate(x, scale_factor=2.0, mode="nearest").double() * 2.0 ** -e
+    assert float(hi.abs().max()) < 32768.0 * 1.0001                      # hi never reaches the clamp
+    assert bool(((hi + lo - want).abs() <= want.abs() * 2.0 ** -21 + 2.0 ** -24).all())
+    w = ((torch.rand(Nout, C, 3, 3, generator=g) * 2 - 1) / (9 * C) ** 0.5).to(dev)
+    b = (torch.randn(Nout, generator=g) * peak * 0.01).to(dev)
+    ws, sc = ops.split_conv_weight(w)
+    got = ops.conv3x3_f32out(s, ws, b, None, sc, act_absmax=am)
+    ref64 = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1)
+    prev = torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False
+    try:
+        ref32 = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest").contiguous(), w, b, padding=1)
+    finally:
+        torch.backends.cudnn.enabled = prev
+    assert bool(torch.isfinite(got).all())
+    e_got, e_lib = _rel(got, ref64), _rel(ref32, ref64)
+    assert e_got <= max(2.0 * e_lib, 6e-7), (peak, e_got, e_lib)
+    assert torch.equal(got, ops.conv3x3_f32out(s, ws, b, None, sc, act_absmax=am))
+
+
+@pytest.mark.gpu
+def test_vae_upsampler_on_a_stream_beyond_fp16_range_matches_the_library():
+    """The product path itself (models.Upsample2D, vae=True): the real SDXL decoder stream exceeds fp16's range; the split path must stay
+    finite and fp32-accurate there."""
+    from elasticdiffusion_official_amd import models as M
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    up = M.Upsample2D(128, vae=True).to(dev).eval().requires_grad_(False)
+    x = torch.randn(2, 128, 16, 24, device=dev) * 5.0e4
+    x[0, 0, 0, 0], x[1, 5, 3, 3] = 4.0e5, -2.9e5
+    want = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), up.conv.weight.double(), up.conv.bias.double(), padding=1)
+    saved = M.VAE_SPLIT_CONV
+    try:
+        M.VAE_SPLIT_CONV = False
+        lib = up(x)
+        M.VAE_SPLIT_CONV = True
+        got = up(x)
+    finally:
+        M.VAE_SPLIT_CONV = saved
+    assert bool(torch.isfinite(got).all())
+    e, elib = _rel(got, want), _rel(lib, want)
+    assert e <= max(2.0 * elib, 6e-7), (e, elib)
+
+
+@pytest.mark.gpu
+def test_groupnorm_split_output_saturates_instead_of_overflowing():
+    """GroupNorm + SiLU bounds its output by the affine parameters; a pathological gamma must still give a finite operand (hi and lo
+    clamp at +-65504) instead of hi = inf, lo = -inf."""
+    from elasticdiffusion_official_amd import ops
+    dev = "cuda:0"
+    C, G = 128, 32
+    x = torch.randn(1, C, 8, 8, device=dev).contiguous(memory_format=torch.channels_last)
+    gamma = torch.full((C,), 1.0e5, device=dev)
+    beta = torch.zeros(C, device=dev)
+    s = ops.groupnorm_nhwc_f32(x, gamma, beta, G, 1e-6, silu=False, split=True)
+    assert bool(torch.isfinite(s.float()).all())
+    y = ops.groupnorm_nhwc_f32(x, gamma, beta, G, 1e-6, silu=False, split=False)
+    hi, lo = s[:, :C].double(), s[:, C:2 * C].double()
+    inside = y.abs() <= 65504
+    assert bool(((hi + lo - y.double()).abs()[inside] <= y.double().abs()[inside] * 2.0 ** -21 + 2.0 ** -24).all())
+    assert bool(((hi + lo).abs()[~inside] >= 65504).all())
+
+
+def test_split_weight_cache_key_tells_a_replaced_parameter_apart():
+    """a fresh Parameter at a recycled address (same data_ptr, version 0) must not hit the cached split weights."""
+    from elasticdiffusion_official_amd import models as M
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1)
+    w0 = conv.weight
+    k0 = (id(w0), w0.data_ptr(), w0._version, str(w0.device))
+    conv.weight = torch.nn.Parameter(w0.detach().clone())
+    w1 = conv.weight
+    assert (id(w1), w1.data_ptr(), w1._version, str(w1.device)) != k0
+    import inspect
+    assert "id(w)" in inspect.getsource(M._split_weight)
+    assert M.prepare_vae_split(torch.nn.Sequential(conv)) == 0     # CPU weights: nothing to pre-split, no error

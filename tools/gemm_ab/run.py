@@ -15,7 +15,7 @@ from elasticdiffusion_official_amd import _hip
 
 
 def load(name):
-    L = ctypes.CDLL(os.path.join(HERE, name))
+    L = ctypes.CDLL(name if os.path.isabs(name) or os.sep in name else os.path.join(HERE, name))
     for fn in ("ed_geglu_gemm", "ed_linear", "ed_conv3x3_nhwc"):
         getattr(L, fn).argtypes = _hip.SIGNATURES[fn]
         getattr(L, fn).restype = ctypes.c_int
@@ -36,8 +36,10 @@ def timed(fn, n=10):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--prev", default="libgemm_prev.so", help="a file in tools/gemm_ab/, or a path (round 6: tools/ab/libelastic_hip_r5.so = the round-5 library)")
+ap.add_argument("--new", default="libgemm_new.so", help="... or a path (elasticdiffusion_official_amd/libelastic_hip.so = the product)")
 a = ap.parse_args()
-libs = {"prev": load("libgemm_prev.so"), "new": load("libgemm_new.so")}
+libs = {"prev": load(a.prev), "new": load(a.new)}
 st = lambda: torch.cuda.current_stream().cuda_stream   # noqa: E731
 g = torch.Generator().manual_seed(0)
 dt, cl = torch.float16, torch.channels_last
