@@ -179,3 +179,33 @@ def test_g9_rng_event_trace(golden_dir, name):
         orc.generate_latent("p", "", height=c["H"], width=c["W"], num_inference_steps=c["steps"],
                             resampling_steps=c["R"], **cases.E2E_KW)
     assert tr.events == want
+
+
+def test_g12_long_schedule_fixture_belongs_to_the_seeded_weights_and_the_oracle(golden_dir):
+    """tests/golden/g12_long_schedule.npz (the REFERENCE's latent after a full 50-step schedule driving the reduced-width SDXL modules,
+    tests/golden/make_long_schedule.py): the seeded weights built here are the fixture's (fingerprint), the stored oracle trace ends in the
+    reference's latent, and the first two timesteps of the oracle -- all a few-minute CPU suite can afford of the 10-minute run --
+    reproduce the first checkpoint.  (The -m gpu test test_full_schedule_fp16_vs_reference_latent holds the product to it.)"""
+    import os
+
+    import numpy as np
+    import torch
+    from oracle.ddim import DDIMOracle
+    from oracle.elastic_oracle import ElasticOracle
+    from tests import realarch as R
+    from tests.golden.make_long_schedule import CASE, CHECKPOINTS, weight_fingerprint
+
+    g = np.load(os.path.join(golden_dir, "g12_long_schedule.npz"))
+    assert np.array_equal(g["oracle_trace"][-1], g["reference_latent"]) and tuple(g["checkpoints"]) == tuple(CHECKPOINTS)
+    assert g["reference_latent"].shape == (1, 4, CASE["H"] // 8, CASE["W"] // 8) and np.isfinite(g["reference_latent"]).all()
+    unet, vae, _ = R.build_small(CASE["sd"])
+    fp = weight_fingerprint(unet, vae)
+    assert abs(fp - float(g["weight_fingerprint"])) <= 1e-9 * abs(fp)
+    orc = ElasticOracle(unet, vae, DDIMOracle(), R.embed_fn(True), sd_version=CASE["sd"], view_batch_size=CASE["vbs"], pooled_dim=32)
+    orc.seed_everything(CASE["seed"])
+    trace = []
+    orc.generate_latent("p", "", height=CASE["H"], width=CASE["W"], num_inference_steps=CASE["steps"], resampling_steps=CASE["R"],
+                        trace=trace, progress=lambda ts: list(ts)[:CHECKPOINTS[0]], **R.LOOP_KW)
+    got, want = trace[CHECKPOINTS[0] - 1], torch.from_numpy(g["oracle_trace"][0])
+    # same torch build, same container: bit-identical in practice; the bar leaves room for a host with another BLAS / thread count
+    assert float((got - want).norm() / want.norm()) < 1e-5

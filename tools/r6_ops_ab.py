@@ -1,0 +1,95 @@
+"""Round 6: ops-level A/B of two builds of libelastic_hip.so in ONE process (ops.py looks the entry point up in `_hip.lib()` at every
+call, so swapping `_hip._LIB` swaps the kernels): flash attention at the UNet's self-attention shapes (the one-vote lazy loop), the
+channels-last GroupNorm at the UNet's shapes (block size per column count, >= 8 blocks per CU, separate finalize launch) and, with
+--gelu, the GEGLU GEMM.  Interleaved rounds, median; outputs compared bit for bit (attention, GEGLU) / against fp32 torch (GroupNorm:
+the chunking changed, so the fp32 partial sums differ in the last bit).
+
+    python tools/r6_ops_ab.py --prev tools/ab/libelastic_hip_r5.so [--new product] [--rounds 7] [--only attn,gn]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+import elasticdiffusion_official_amd  # noqa: F401
+from elasticdiffusion_official_amd import _hip, ops
+from tools.fwd_ab import load
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3      # us
+
+
+def ab(name, libs, fn, rounds, extra=None, check=None):
+    outs, t = {}, {k: [] for k in libs}
+    for k, L in libs.items():
+        _hip._LIB = L
+        outs[k] = fn().clone()
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for k, L in libs.items():
+            _hip._LIB = L
+            t[k].append(timed(fn))
+    med = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
+    rec = {"case": name, "prev_us": round(med["prev"], 1), "new_us": round(med["new"], 1), "speedup": round(med["prev"] / med["new"], 4),
+           "bit_identical": bool(torch.equal(outs["prev"], outs["new"]))}
+    if extra:
+        rec.update({k: round(v / med["new"], 1) for k, v in extra.items()})
+    if check is not None:
+        rec.update(check(outs))
+    print(json.dumps(rec), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prev", default="tools/ab/libelastic_hip_r5.so")
+    ap.add_argument("--new", default="product")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--only", default="attn,gn")
+    a = ap.parse_args()
+    product = _hip.lib()
+    libs = {"prev": load(a.prev), "new": load(a.new)}
+    dev, dt = "cuda", torch.float16
+    g = torch.Generator().manual_seed(0)
+    only = set(a.only.split(","))
+    if "attn" in only:
+        for (B, H, N) in [(20, 10, 4096), (20, 20, 1024), (6, 10, 4096), (6, 20, 1024)]:
+            q, k, v = (torch.randn(B, N, H * 64, generator=g).to(dev, dt) for _ in range(3))
+            flops = 4.0 * B * H * N * N * 64
+            ab(f"flash_attention self B{B} H{H} N{N}", libs, lambda: ops.flash_attention(q, k, v, H), a.rounds,
+               extra={"new_tflops": flops / 1e6})
+        # a row whose maximum jumps late: the slow path of the one-vote loop (redo + rescale in one branch)
+        B, H, N = 2, 10, 1024
+        q, k, v = (torch.randn(B, N, H * 64, generator=g).to(dev, dt) for _ in range(3))
+        k[:, 700:703] *= 12.0
+        ref = F.scaled_dot_product_attention(*(t.view(B, N, H, 64).transpose(1, 2).float() for t in (q, k, v))).transpose(1, 2).reshape(B, N, H * 64)
+        ab("flash_attention late-maximum rows", libs, lambda: ops.flash_attention(q, k, v, H), 3,
+           check=lambda o: {"new_max_abs_err_vs_fp32": float((o["new"].float() - ref).abs().max())})
+    if "gn" in only:
+        cl = torch.channels_last
+        for shape in [(20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1920, 64, 64), (20, 1280, 32, 32), (20, 2560, 32, 32),
+                      (6, 320, 128, 128), (6, 640, 64, 64), (6, 1280, 32, 32)]:
+            x = torch.randn(*shape, generator=g).to(dev, dt).contiguous(memory_format=cl)
+            C = shape[1]
+            w, b = (torch.randn(C, generator=g) * 0.2 + 1).to(dev, dt), (torch.randn(C, generator=g) * 0.1).to(dev, dt)
+            want = F.silu(F.group_norm(x.float(), 32, w.float(), b.float(), 1e-5))
+            ab(f"groupnorm_nhwc {list(shape)}", libs, lambda: ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=True), a.rounds,
+               extra={"new_gbs": 3.0 * x.numel() * 2 / 1e3},
+               check=lambda o: {k_ + "_max_err_vs_fp32": float((o[k_].float() - want).abs().max()) for k_ in ("prev", "new")})
+    _hip._LIB = product
+
+
+if __name__ == "__main__":
+    main()
