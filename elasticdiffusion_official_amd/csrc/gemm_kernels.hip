@@ -154,19 +154,29 @@ struct Ctx {
 };
 
 // position of a K tile (wave-uniform).  GEMM: k = 64 tile.  CONV (3x3, stride 1, pad 1, NHWC): K = 9 taps x Cin, tile -> (tap, 64-channel
-// block ct); the A operand row of output pixel m at tap (dy, dx) is the Cin vector of pixel m + dy W + dx, or zeros outside the image
+// block ct); the A operand row of output pixel m at tap (dy, dx) is the Cin vector of pixel m + dy W + dx, or zeros outside the image.
+// `tile` is the position in the WALK, `w` the K-tile index into W's rows (= tap cpt + ct; = tile for a GEMM).
+// Round 6: the convolution walks CHANNEL-BLOCK-major -- all 9 taps of channel block 0, then of block 1, ... -- instead of tap-major.
+// The 9 taps of one channel block read the same 128-byte segments of a tile's (256 + halo) pixels, shifted by a pixel or an image row:
+// ~64 KB per tile that stays in L2 across the 9 K tiles and is never needed again, where the tap-major walk came back to every pixel's
+// whole Cin vector (328 KB per tile at 128 x 128 x 320, 10 MB for the 32 tiles an XCD runs against 4 MiB of L2) nine times: PMC
+// FETCH_SIZE 6.8 x the algorithmic bytes (profiles/r5_unet_pmc.json).  Same products, another summation order.
 struct KPos {
-  int tile, tap, ct;
+  int tile, tap, ct, w;
 };
 template <bool CONV>
 __device__ __forceinline__ KPos k_next(KPos p, int cpt) {
   ++p.tile;
   if (CONV) {
-    ++p.ct;
-    if (p.ct == cpt) {
-      p.ct = 0;
-      ++p.tap;
+    ++p.tap;
+    p.w += cpt;
+    if (p.tap == 9) {
+      p.tap = 0;
+      ++p.ct;
+      p.w = p.ct;
     }
+  } else {
+    p.w = p.tile;
   }
   return p;
 }
@@ -191,9 +201,9 @@ __device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, KPos p, int 
   }
 }
 template <int BUFI>
-__device__ __forceinline__ void stage_w(uint8_t* lds, const Ctx& c, int tile, int g) {
+__device__ __forceinline__ void stage_w(uint8_t* lds, const Ctx& c, int widx, int g) {    // widx = KPos::w of the K tile
   const int rg = 8 * g + c.wave;                              // value row groups 0..7, gate row groups 8..15
-  const int vo = c.w_voff[g] + tile * (BK * 2);
+  const int vo = c.w_voff[g] + widx * (BK * 2);
   uint8_t* dst = lds + BUFI * BUF + w_sub(0, 0) + rg * (2 * SUB);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(c.wr_, (lds_ptr_t)(dst + SUB), 16, vo + 64, 0, 0, 0);
@@ -266,7 +276,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   ED_BARRIER();
   // ---- phase 2: m half 0 x gate
   read_w<T, BUFI, 1>(lds, c, f);
-  if (s2) stage_w<BUFI>(lds, c, tile + 2, 0);           // value rows of tile + 2 (read in phase 1, retired before its barrier)
+  if (s2) stage_w<BUFI>(lds, c, p2.w, 0);           // value rows of tile + 2 (read in phase 1, retired before its barrier)
   if (FIRST) ED_WAIT_VM(10);
   ED_BARRIER();
   ED_WAIT_LGKM(0);
@@ -284,7 +294,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
   ED_BARRIER();
   // ---- phase 4: m half 1 x value (fragments already in registers)
   if (s2) {
-    stage_w<BUFI>(lds, c, tile + 2, 1);                 // gate rows of tile + 2 (read in phase 2)
+    stage_w<BUFI>(lds, c, p2.w, 1);                 // gate rows of tile + 2 (read in phase 2)
     ED_WAIT_VM(6);                                      // all of tile + 1 has landed; 3 half tiles of tile + 2 stay in flight
   } else {
     ED_WAIT_VM(0);                                      // last two tiles: nothing newer to leave in flight
@@ -320,9 +330,9 @@ __device__ __forceinline__ void tile_phases_two(uint8_t* lds, const Ctx& c, Frag
   ED_BARRIER();
   read_x<T, BUFI>(lds, c, f, 1);
   if (s2) {
-    stage_w<BUFI>(lds, c, tile + 2, 0);
+    stage_w<BUFI>(lds, c, p2.w, 0);
     stage_x<BUFI, CONV>(lds, c, p2, 0);
-    stage_w<BUFI>(lds, c, tile + 2, 1);
+    stage_w<BUFI>(lds, c, p2.w, 1);
     ED_WAIT_VM(6);
   } else {
     ED_WAIT_VM(0);
@@ -357,7 +367,7 @@ __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Fra
   ED_BARRIER();
   read_x<T, BUFI>(lds, c, f, 1);
   if (s2) {
-    stage_w<BUFI>(lds, c, tile + 2, 0);
+    stage_w<BUFI>(lds, c, p2.w, 0);
     stage_x<BUFI, CONV>(lds, c, p2, 0);
     ED_WAIT_VM(4);
   } else {
@@ -468,7 +478,7 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
 
   const int nt = K / BK;
   // prologue: all of tile 0, then the three half tiles of tile 1 the loop does not stage itself
-  const KPos p0 = {0, 0, 0};
+  const KPos p0 = {0, 0, 0, 0};
   KPos pa = k_next<CONV>(p0, c.cpt);      // position of tile t + 1
   KPos pb = k_next<CONV>(pa, c.cpt);      // position of tile t + 2
   const bool half = EPI == 1 && n0 + BN >= I;     // wave-uniform: nothing of this tile's second half is inside the output (tile_phases_half)
@@ -477,7 +487,7 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
     stage_x<0, CONV>(lds, c, p0, 0);
     stage_x<0, CONV>(lds, c, p0, 1);
     if (nt > 1) {
-      stage_w<1>(lds, c, 1, 0);
+      stage_w<1>(lds, c, pa.w, 0);
       stage_x<1, CONV>(lds, c, pa, 0);
       ED_WAIT_VM(4);              // all of tile 0 (6 DMAs); tile 1's two half tiles stay in flight
     } else {
@@ -504,9 +514,9 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   constexpr bool two = TWO;               // long K: 4 barrier intervals per K tile (tile_phases_two)
   const bool early = nt >= 3 && !two;     // (every real shape: K >= 320)
   if (nt > 1) {
-    stage_w<1>(lds, c, 1, 0);
+    stage_w<1>(lds, c, pa.w, 0);
     stage_x<1, CONV>(lds, c, pa, 0);
-    stage_w<1>(lds, c, 1, 1);
+    stage_w<1>(lds, c, pa.w, 1);
     if (early) ED_WAIT_VM(10);    // only what phase 1 of tile 0 reads (tile_phases<.., FIRST>)
     else ED_WAIT_VM(6);
   } else {
@@ -698,7 +708,7 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
     }
   };
   auto issue_prologue = [&](const Ctx& c) {   // all of K tile 0, then the three half tiles of K tile 1 the loop does not stage itself
-    const KPos p0 = {0, 0, 0}, p1 = {1, 0, 0};
+    const KPos p0 = {0, 0, 0, 0}, p1 = {1, 0, 0, 1};
     stage_w<0>(lds, c, 0, 0);
     stage_x<0, false>(lds, c, p0, 0);
     stage_w<0>(lds, c, 0, 1);
@@ -724,7 +734,7 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     Frags<T> f;
-    KPos pa = {1, 0, 0}, pb = {2, 0, 0};
+    KPos pa = {1, 0, 0, 1}, pb = {2, 0, 0, 2};
     if (nt > 1) {
       if (early) ED_WAIT_VM(10);
       else ED_WAIT_VM(6);
@@ -737,16 +747,16 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
     int t = 0;
     if (early) {
       tile_phases<T, 0, false, true>(lds, c, f, acc, 0, true, true, pa, pb);
-      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0, pb.tile + 1};
       tile_phases<T, 1, false>(lds, c, f, acc, 1, true, 3 < nt, pa, pb);
-      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0, pb.tile + 1};
       t = 2;
     }
     for (; t + 1 < nt; t += 2) {
       tile_phases<T, 0, false>(lds, c, f, acc, t, true, t + 2 < nt, pa, pb);
-      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0, pb.tile + 1};
       tile_phases<T, 1, false>(lds, c, f, acc, t + 1, t + 2 < nt, t + 3 < nt, pa, pb);
-      pa = pb, pb = KPos{pb.tile + 1, 0, 0};
+      pa = pb, pb = KPos{pb.tile + 1, 0, 0, pb.tile + 1};
     }
     if (t < nt) tile_phases<T, 0, false>(lds, c, f, acc, t, false, false, pa, pb);
     if (wrow == 0) ED_BARRIER();

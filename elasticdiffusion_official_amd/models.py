@@ -44,11 +44,61 @@ def _fusable_nhwc(x):
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
 
 
+# ---- fp32 residual stream under a 16-bit model (round 6, ``UNet2DConditionModel.residual_fp32``) ---------------------------------------
+# The tolerance mode for configurations whose fp16 latent ends outside north_star's 1e-3 (cfg2, SD 1.5 512 x 1024: 1.09e-3 against the
+# fp32 loop, profiles/bench_r6_s1_cfg2_fp32leg.json): the tensor that persists from block to block -- x in `x = x + branch(norm(x))` -- is
+# kept in fp32, every branch still computes in the 16-bit model dtype (same MFMA kernels, same weights), i.e. the adds no longer round
+# (a third of the 16-bit loop's drift by profiles/r5_precision_attribution.json).  Everything that READS the stream takes fp32 in and
+# hands the model dtype on: the normalisation layers through torch ops in this mode (their HIP kernels are 16-bit in / out), the
+# up / down-sampling and shortcut convolutions after a cast; everything that WRITES it adds a 16-bit branch result to the fp32 stream.
+def _stream32(x, module_dtype):
+    """is ``x`` an fp32 residual stream feeding a module whose parameters are 16-bit?"""
+    return x.dtype == torch.float32 and module_dtype in (torch.float16, torch.bfloat16)
+
+
+def _f32_params(norm):
+    """fp32 copies of a normalisation layer's (weight, bias), rebuilt when they change"""
+    w, b = norm.weight, norm.bias
+    key = (id(w), w.data_ptr(), w._version, id(b), b._version)
+    hit = norm.__dict__.get("_p32")
+    if hit is None or hit[0] != key:
+        hit = (key, w.detach().float(), b.detach().float())
+        norm.__dict__["_p32"] = hit
+    return hit[1], hit[2]
+
+
+def _f32_bias(mod):
+    """fp32 copy of a module's bias (None without one), rebuilt when it changes"""
+    b = mod.bias
+    if b is None:
+        return None
+    key = (id(b), b.data_ptr(), b._version)
+    hit = mod.__dict__.get("_b32")
+    if hit is None or hit[0] != key:
+        hit = (key, b.detach().float())
+        mod.__dict__["_b32"] = hit
+    return hit[1]
+
+
 def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=None):
     """GroupNorm [+ SiLU] [-> (N, H*W, C) token layout] of ``x``, or of ``(x + conv_bias[c]) + chan_bias[n, c]``: the
     bias of the (bias-free) convolution that produced x and the time-embedding add of ResnetBlock2D, folded into the
     kernel.  HIP: ed_groupnorm / ed_groupnorm_nhwc; torch otherwise."""
     N, C, H, W = x.shape
+    if _stream32(x, norm.weight.dtype):   # fp32 residual stream: statistics and affine in fp32, the result in the model dtype
+        dt = norm.weight.dtype
+        if conv_bias is not None:
+            x = x + conv_bias[None, :, None, None]
+        if chan_bias is not None:
+            x = x + chan_bias[:, :, None, None]
+        w32, b32 = _f32_params(norm)
+        y = F.group_norm(x, norm.num_groups, w32, b32, norm.eps)
+        if silu:
+            y = F.silu(y)
+        y = y.to(dt)
+        if CHANNELS_LAST and y.is_cuda:
+            y = y.contiguous(memory_format=torch.channels_last)
+        return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y
     cpg = C // norm.num_groups
     nhwc = _fusable_nhwc(x) and C % 8 == 0 and cpg >= 8
     if (chan_bias is not None or conv_bias is not None) and not (
@@ -213,6 +263,9 @@ def prepare_vae_split(vae):
 def layer_norm(norm, x):
     """LayerNorm over the last dim.  HIP: ed_layernorm (one wave per row); torch otherwise."""
     D = x.shape[-1]
+    if norm.elementwise_affine and _stream32(x, norm.weight.dtype):   # fp32 residual stream -> model dtype
+        w32, b32 = _f32_params(norm)
+        return F.layer_norm(x, (D,), w32, b32, norm.eps).to(norm.weight.dtype)
     if FUSED_LAYERNORM and _fusable(x) and D % 8 == 0 and D <= 2048 and norm.elementwise_affine:
         from . import ops
         return ops.layernorm(x, norm.weight, norm.bias, norm.eps)
@@ -226,7 +279,7 @@ def add_layer_norm(norm, a, b):
             and norm.elementwise_affine):
         from . import ops
         return ops.add_layernorm(a, b, norm.weight, norm.bias, norm.eps)
-    s = a + b
+    s = a + b          # (fp32 residual stream: a 16-bit branch result + the fp32 stream -> fp32)
     return s, layer_norm(norm, s)
 
 
@@ -278,6 +331,32 @@ class ResnetBlock2D(nn.Module):
         tb = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
         sc = self.conv_shortcut
         cout = self.conv1.out_channels
+        if _stream32(x, self.conv1.weight.dtype):
+            # fp32 residual stream (UNet2DConditionModel.residual_fp32): both branches in the model dtype -- the same GroupNorm -> convolution
+            # kernels from norm1's output on -- and ONE fp32 add onto the stream
+            a = group_norm_act(self.norm1, x, silu=True)
+            if _hip_conv3x3(a, self.conv1) and _hip_conv3x3(a[:, :1].expand(-1, cout, -1, -1), self.conv2, shape_only=True) \
+                    and cout % 8 == 0 and cout // self.norm2.num_groups >= 8:
+                from . import ops
+                h = ops.conv3x3_nhwc(a, self.conv1.weight, self.conv1.bias, sample_bias=None if tb is None else tb.contiguous())
+                a2 = group_norm_act(self.norm2, h, silu=True)
+                B_, _, H_, W_ = a2.shape
+                if a2.dtype == torch.float16 and ops.conv3x3_f32out_ok(B_, H_, W_, cout, cout):
+                    # conv2 through the fp32-output epilogue (ed_conv3x3_nhwc_f32out: fp16 operands, fp32 bias / residual / result): the
+                    # branch result is never rounded to 16 bits and the add onto the stream costs no pass of its own
+                    res = x if sc is None else linear_(x.to(h.dtype).permute(0, 2, 3, 1), sc.weight.reshape(cout, -1), sc.bias).permute(0, 3, 1, 2).float()
+                    res = res.contiguous(memory_format=torch.channels_last)
+                    return ops.conv3x3_f32out(a2, self.conv2.weight, _f32_bias(self.conv2), res, 1.0)
+                h = ops.conv3x3_nhwc(a2, self.conv2.weight, self.conv2.bias)
+            else:
+                h = self.conv1(a)
+                h = self.conv2(group_norm_act(self.norm2, h, silu=True, chan_bias=tb))
+            if sc is None:
+                return x + h
+            xs = x.to(h.dtype)
+            res = (linear_(xs.permute(0, 2, 3, 1), sc.weight.reshape(cout, -1), sc.bias).permute(0, 3, 1, 2)
+                   if xs.is_contiguous(memory_format=torch.channels_last) and not xs.is_contiguous() else sc(xs))
+            return res.float() + h
         cl = _fusable_nhwc(x) and cout % 8 == 0 and cout // self.norm2.num_groups >= 8
         # both norms must take the channels-last HIP kernel (its torch fallback hands back an NCHW tensor the convolution
         # wrapper rejects) and BOTH convolutions must be shapes the kernel takes: conv2's Cin is cout
@@ -489,10 +568,15 @@ class Transformer2DModel(nn.Module):
             h = linear_(group_norm_act(self.norm, x, tokens=True), self.proj_in.weight, self.proj_in.bias)
         else:
             h = self.proj_in(group_norm_act(self.norm, x)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        s32 = _stream32(x, self.proj_out.weight.dtype)
+        if s32:
+            h = h.float()      # the blocks' own residual stream in fp32 as well (their LayerNorms hand the model dtype to the branches)
         pend = None
         for blk in self.transformer_blocks:
             pend, h = blk(h, context, pend, kv)
         h = pend + h
+        if s32:
+            h = h.to(self.proj_out.weight.dtype)
         if self.linear_proj:
             h = linear_(h, self.proj_out.weight, self.proj_out.bias)
             if (FUSED_TOKENS_ADD and _fusable(x) and _fusable(h) and C % 64 == 0 and (H * W) % 64 == 0):
@@ -513,6 +597,8 @@ class Downsample2D(nn.Module):
     def forward(self, x):
         if self.padding == 0:  # VAE encoder: asymmetric pad (diffusers Downsample2D)
             x = F.pad(_to_nchw(x), (0, 1, 0, 1))
+        if _stream32(x, self.conv.weight.dtype):   # fp32 residual stream: the convolution in the model dtype, its result widened (exact)
+            return self.conv(x.to(self.conv.weight.dtype)).float()
         return self.conv(x)
 
 
@@ -532,6 +618,8 @@ class Upsample2D(nn.Module):
         return C % 64 == 0 and 4 * H * W * 3 * C * 2 < 2 ** 31 - 16     # per sample; larger batches are processed in slices
 
     def forward(self, x):
+        if _stream32(x, self.conv.weight.dtype):   # fp32 residual stream of a 16-bit UNet
+            return self.forward(x.to(self.conv.weight.dtype)).float()
         if x.dtype == torch.float32:
             if self._split_ok(x):
                 # the VAE decoder's upsampler on the MFMA pipe (VAE_SPLIT_CONV): the raw stream is split (scaled by a per-tensor power of
@@ -711,6 +799,8 @@ class UNet2DConditionModel(nn.Module):
         ctx = encoder_hidden_states.to(self.dtype)
         emb = self.embed(x, timestep, added_cond_kwargs)
         x = self.conv_in(x)
+        if getattr(self, "residual_fp32", False) and x.dtype != torch.float32:
+            x = x.float()      # from here to conv_norm_out the residual stream is fp32 (see _stream32)
         skips = [x]
         for blk in self.down_blocks:
             x, outs = blk(x, emb, ctx, cross_kv)

@@ -129,14 +129,15 @@ def run_oracle(case, unet, vae, cn):
     return trace, torch.rand(4)
 
 
-def run_product(case, unet, vae, cn, dtype, device="cuda:0"):
-    """The HIP product path with copies of the given modules on the GPU (UNet/ControlNet in ``dtype``, VAE fp32)."""
+def run_product(case, unet, vae, cn, dtype, device="cuda:0", residual_fp32=False):
+    """The HIP product path with copies of the given modules on the GPU (UNet/ControlNet in ``dtype``, VAE fp32).
+    ``residual_fp32``: the round-6 tolerance mode (fp32 residual stream under the 16-bit branches)."""
     from elasticdiffusion_official_amd import ElasticDiffusion
     c = REAL_CASES[case] if isinstance(case, str) else case
     xl = c["sd"].startswith("XL")
     pipe = ElasticDiffusion(device, c["sd"], view_batch_size=c["vbs"], unet=copy.deepcopy(unet).to(dtype),
                             vae=copy.deepcopy(vae), controlnet=None if cn is None else copy.deepcopy(cn).to(dtype),
-                            text_encoder=embed_fn(xl))
+                            text_encoder=embed_fn(xl), residual_fp32=residual_fp32)
     kw = dict(LOOP_KW)
     if cn is not None:
         ds = pipe.get_downsample_size(c["H"], c["W"])

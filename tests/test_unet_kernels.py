@@ -125,6 +125,25 @@ def test_groupnorm_channels_last(dtype, N, C, H, W, silu):
                        ops.groupnorm_nhwc(pre, w, b, 32, 1e-5, silu=silu))
 
 
+@pytest.mark.parametrize("N,C,H,W", [(20, 1280, 32, 32), (6, 640, 64, 64), (3, 320, 128, 128), (5, 2560, 32, 32)])
+def test_groupnorm_channels_last_at_the_unet_shapes_many_chunks(N, C, H, W):
+    """Round 6 launch plan (gn_plan): block size = the column count rounded to whole waves (C = 1280: 192 threads), ~2048 blocks per launch,
+    statistics finalised by a separate N-block launch -- many chunks per sample, chunk boundaries inside image rows, two columns per thread
+    (C = 2560).  Against fp32 torch, and launch-to-launch bit-identical (fixed summation order, no atomics)."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator().manual_seed(C + N)
+    x = (torch.randn(N, C, H, W, generator=g) * 2.1 - 0.4).to(DEV, torch.float16).contiguous(memory_format=torch.channels_last)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV, torch.float16)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV, torch.float16)
+    got = ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=True)
+    ref = F.silu(F.group_norm(x.float(), 32, w.float(), b.float(), 1e-5))
+    ulp = 2.0 ** -11
+    err = (got.float() - ref).abs()
+    assert bool((err <= 2.0 * ulp * ref.abs() + 4 * ulp).all()), float(err.max())
+    for _ in range(3):
+        assert torch.equal(got, ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=True))
+
+
 def test_unet_channels_last_path_close():
     """The whole (small) UNet with channels-last activations + NHWC GroupNorm vs the default NCHW path."""
     from elasticdiffusion_official_amd import models as M

@@ -128,16 +128,22 @@ class Block:
         return out
 
     def k_pos(self, tile):
-        """KPos of the .hip file, derived from the tile index (the kernel advances it incrementally: k_next)."""
+        """KPos of the .hip file, derived from the position in the walk (the kernel advances it incrementally: k_next).  Round 6: the
+        convolution walks channel-block-major -- the 9 taps of channel block 0, then of block 1, ... (L2 reuse across the taps)."""
         pos = (0, 0, 0)
         for _ in range(tile):                       # k_next of the .hip file
             t, tap, ct = pos
-            t, ct = t + 1, ct + 1 if self.conv else ct
-            if self.conv and ct == self.cpt:
-                ct, tap = 0, tap + 1
+            t, tap = t + 1, tap + 1 if self.conv else tap
+            if self.conv and tap == 9:
+                tap, ct = 0, ct + 1
             pos = (t, tap, ct)
-        assert pos == ((tile, tile // self.cpt, tile % self.cpt) if self.conv else (tile, 0, 0))
+        assert pos == ((tile, tile % 9, tile // 9) if self.conv else (tile, 0, 0))
         return pos
+
+    def w_index(self, tile):
+        """KPos::w -- the K-tile index into W's rows ([N, 3, 3, Cin]: k = tap Cin + channel) of walk position `tile`"""
+        _, tap, ct = self.k_pos(tile)
+        return tap * self.cpt + ct if self.conv else tile
 
     def land(self, base, vals):
         e0 = base // 2
@@ -196,7 +202,7 @@ class Block:
 
     def stage_w(self, wv, bufi, tile, g):
         rg = 8 * g + wv.wave
-        vo = wv.w_voff[g] + tile * (BK * 2)
+        vo = wv.w_voff[g] + self.w_index(tile) * (BK * 2)
         dst = bufi * BUF + w_sub(0, 0) + rg * (2 * SUB)
         self.dma(wv, 1, dst, vo, 0)
         self.dma(wv, 1, dst + SUB, vo + 64, 0)
@@ -335,7 +341,7 @@ class Block:
         elif s2:
             g = 0 if op == 1 else 1
             rg = 8 * g + wv.wave
-            self.dma(wv, 1, bufi * BUF + w_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.w_voff[g] + (tile + 2) * (BK * 2) + 64 * k, 0)
+            self.dma(wv, 1, bufi * BUF + w_sub(0, 0) + rg * (2 * SUB) + k * SUB, wv.w_voff[g] + self.w_index(tile + 2) * (BK * 2) + 64 * k, 0)
 
     def tile_segments_sched(self, wv, bufi, tile, s1, s2, sched, first=False):
         slot, two = SCHEDS[sched][0], SCHEDS[sched][2]
