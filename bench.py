@@ -531,7 +531,7 @@ def main():
             # PMC traffic is measured offline (rocprofv3 --pmc passes, profiles/): one file per workload, newest round first;
             # a workload without a committed PMC pass reports traffic null rather than another workload's bytes
             pmc, pmc_file = None, None
-            for fname in (f"r5_unet_pmc_{args.workload}.json", "r5_unet_pmc.json", f"r4_unet_pmc_{args.workload}.json", "r4_unet_pmc.json", f"r3_unet_pmc_{args.workload}.json",
+            for fname in (f"r6_unet_pmc_{args.workload}.json", "r6_unet_pmc.json", f"r5_unet_pmc_{args.workload}.json", "r5_unet_pmc.json", f"r4_unet_pmc_{args.workload}.json", "r4_unet_pmc.json", f"r3_unet_pmc_{args.workload}.json",
                           "r3_unet_pmc.json", "r2_unet_pmc.json"):
                 doc = load_profile_json(fname)
                 if doc and doc.get("workload", "sdxl_1024x2048") == args.workload and dom in doc.get("kernels", {}):

@@ -46,6 +46,9 @@ SIGNATURES = {
     "ed_add_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
     "ed_tokens_add_nchw": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ed_layernorm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
+    "ed_layernorm_s32": [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
+    "ed_add_layernorm_s32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp],
+    "ed_groupnorm_nhwc_s32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc_workspace": [_i, _i, _i, _i],
     "ed_assemble_rows": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,

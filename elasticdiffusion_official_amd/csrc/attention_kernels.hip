@@ -695,12 +695,9 @@ k_flash_attn_pipe(const Params p) {
                                                                                           hi, qf, s_cur, s_next, p_prev, p_cur,
                                                                                           oacc, sl, run, negm);
     if (lazy) {
-      // ONE vote per lazy tile (round 6; two until round 5: the sum check and then `any alpha != 1`, which on this path can only be true
-      // when the sum check was): the rare slow path redoes the tile exactly AND rescales O in the same branch; the common path is
-      // l += psum.  Same arithmetic in both paths as before (alpha = 1: l * 1 + psum = l + psum exactly).
+      run.alpha = 1.0f;
       if (__any(!(run.psum <= RESCALE_SUM_MAX))) {  // (also catches inf / NaN sums)
         const float mb_old = run.mb;
-        run.alpha = 1.0f;
         resoftmax_tile<T>(sm.k[kb_cur], ln, hi, qf, s_cur, sl, run, p_cur);
         if (EXP2) {  // S(t+1) was started from the old reference: move it (and the next chains' start) to the new one
           const float d = run.mb - mb_old;
@@ -712,16 +709,10 @@ k_flash_attn_pipe(const Params p) {
           for (int i = 0; i < 16; ++i) negm[i] = -run.mb;
           asm volatile("" : "+v"(negm));
         }
-        run.l = __builtin_fmaf(run.l, run.alpha, run.psum);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          oacc[0][i] *= run.alpha;
-          oacc[1][i] *= run.alpha;
-        }
-      } else {
-        run.l += run.psum;
       }
-    } else if (__any(run.alpha != 1.0f)) {  // exact softmax: first tile, or a row's maximum grew by more than 2^RESCALE_LOG2 (rare)
+      run.l = __builtin_fmaf(run.l, run.alpha, run.psum);
+    }
+    if (__any(run.alpha != 1.0f)) {  // first tile, or a row's maximum grew by more than 2^RESCALE_LOG2 (rare)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         oacc[0][i] *= run.alpha;

@@ -381,9 +381,48 @@ __device__ __forceinline__ void gn_accumulate(const U16x8& v, const U16x8& kbv, 
   }
 }
 
-template <typename T>
+// X32 (round 6, the fp32-residual-stream mode of the UNet): x is an fp32 [N, HW, C] tensor -- 8 channels = two 16-byte loads -- and there
+// are no folded biases; statistics, affine and output type are unchanged (the result is the 16-bit operand of the next GEMM).
+template <bool X32>
+struct Row8 {      // 8 consecutive channels of one pixel as loaded
+  U16x8 h;
+  float4 lo, hi;
+  __device__ __forceinline__ void load(const void* base, int64_t elem) {
+    if (X32) {
+      const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+      lo = p[0], hi = p[1];
+    } else {
+      h = *reinterpret_cast<const U16x8*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    }
+  }
+  __device__ __forceinline__ float f32(int e) const {   // X32 only
+    return e == 0 ? lo.x : e == 1 ? lo.y : e == 2 ? lo.z : e == 3 ? lo.w : e == 4 ? hi.x : e == 5 ? hi.y : e == 6 ? hi.z : hi.w;
+  }
+};
+
+template <typename T, bool X32>
+__device__ __forceinline__ void gn_accumulate8(const Row8<X32>& v, const U16x8& kbv, bool has_kb, const U16x8& cbv, bool has_cb,
+                                               int split, float& s0, float& q0, float& s1, float& q1) {
+  if (!X32) {
+    gn_accumulate<T>(v.h, kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = v.f32(e);
+    if (e < split) {
+      s0 += f;
+      q0 += f * f;
+    } else {
+      s1 += f;
+      q1 += f * f;
+    }
+  }
+}
+
+template <typename T, bool X32 = false>
 __global__ void __launch_bounds__(GNL_THREADS)
-k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ conv_bias,
+k_gn_nhwc_partial(const void* __restrict__ x, const uint16_t* __restrict__ conv_bias,
                   const uint16_t* __restrict__ chan_bias, float* __restrict__ partial, int C, int HW, int G,
                   int rows_per_block) {
   extern __shared__ float sh[];  // [lanes][VC][4]: (sum, sumsq) of the column's first / second group part
@@ -396,7 +435,7 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
   const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
   const bool active = ncol == 1 ? (int)threadIdx.x < R * VC : true;
   const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
-  const uint16_t* base = x + (int64_t)n * HW * C;
+  const int64_t base = (int64_t)n * HW * C;                   // element offset of the sample
   const uint16_t* cbn = chan_bias ? chan_bias + (int64_t)n * C : nullptr;
   const bool has_cb = cbn != nullptr, has_kb = conv_bias != nullptr;
   if (active) {
@@ -410,19 +449,22 @@ k_gn_nhwc_partial(const uint16_t* __restrict__ x, const uint16_t* __restrict__ c
       if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
       if (has_cb) cbv = *reinterpret_cast<const U16x8*>(cbn + c0);
       float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-      const uint16_t* col = base + c0;
+      const int64_t col = base + c0;
       const int64_t step = (int64_t)R * C;
       int row = r0 + my_r;
-      for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {  // GNL_UNROLL independent 16-byte loads in flight
-        const uint16_t* p0 = col + (int64_t)row * C;
-        U16x8 v[GNL_UNROLL];
+      for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {  // GNL_UNROLL independent (pairs of) 16-byte loads in flight
+        const int64_t p0 = col + (int64_t)row * C;
+        Row8<X32> v[GNL_UNROLL];
 #pragma unroll
-        for (int u = 0; u < GNL_UNROLL; ++u) v[u] = *reinterpret_cast<const U16x8*>(p0 + u * step);
+        for (int u = 0; u < GNL_UNROLL; ++u) v[u].load(x, p0 + u * step);
 #pragma unroll
-        for (int u = 0; u < GNL_UNROLL; ++u) gn_accumulate<T>(v[u], kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
+        for (int u = 0; u < GNL_UNROLL; ++u) gn_accumulate8<T, X32>(v[u], kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
       }
-      for (; row < r1; row += R)
-        gn_accumulate<T>(*reinterpret_cast<const U16x8*>(col + (int64_t)row * C), kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
+      for (; row < r1; row += R) {
+        Row8<X32> v;
+        v.load(x, col + (int64_t)row * C);
+        gn_accumulate8<T, X32>(v, kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
+      }
       float* slot = sh + ((int64_t)my_r * VC + vc) * 4;
       slot[0] = s0, slot[1] = q0, slot[2] = s1, slot[3] = q1;
     }
@@ -493,9 +535,9 @@ k_gn_nhwc_finalize(const float* __restrict__ partial, float* __restrict__ stats_
 
 // Same thread <-> column mapping as the statistics kernel: gamma / beta / folded biases / the (at most two) group statistics of a
 // thread's 8 channels are loaded ONCE and it streams rows, GNL_UNROLL at a time.
-template <typename T, bool ACT>
+template <typename T, bool ACT, bool X32 = false>
 __global__ void __launch_bounds__(GNL_THREADS)
-k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+k_gn_nhwc_apply(const void* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
                 const float* __restrict__ stats_all, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block) {
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -509,7 +551,7 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
   if (ncol == 1 && (int)threadIdx.x >= R * VC) return;
   const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
   const bool has_cb = chan_bias != nullptr, has_kb = conv_bias != nullptr;
-  const uint16_t* xb = x + (int64_t)n * HW * C;
+  const int64_t xb = (int64_t)n * HW * C;                      // element offset of the sample in x
   uint16_t* ob = out + (int64_t)n * HW * C;
 #pragma unroll
   for (int j = 0; j < GNL_MAXCOL; ++j) {
@@ -532,11 +574,12 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
       kb[e] = has_kb ? T::to_f32(kbv.v[e]) : 0.f;
       cb[e] = has_cb ? T::to_f32(cbv.v[e]) : 0.f;
     }
-    auto norm = [&](const U16x8& v) {
+    auto norm = [&](const Row8<X32>& v) {
       U16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float y = T::to_f32(T::from_f32(fmaf(a[e], biased<T>(v.v[e], kb[e], has_kb, cb[e], has_cb), b[e])));
+        const float xin = X32 ? v.f32(e) : biased<T>(v.h.v[e], kb[e], has_kb, cb[e], has_cb);
+        const float y = T::to_f32(T::from_f32(fmaf(a[e], xin, b[e])));
         o.v[e] = ACT ? T::from_f32(silu_fast(y)) : T::from_f32(y);
       }
       return o;
@@ -545,15 +588,17 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
     int row = r0 + my_r;
     for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {
       const int64_t off = (int64_t)row * C + c0;
-      U16x8 v[GNL_UNROLL];
+      Row8<X32> v[GNL_UNROLL];
 #pragma unroll
-      for (int u = 0; u < GNL_UNROLL; ++u) v[u] = *reinterpret_cast<const U16x8*>(xb + off + u * step);
+      for (int u = 0; u < GNL_UNROLL; ++u) v[u].load(x, xb + off + u * step);
 #pragma unroll
       for (int u = 0; u < GNL_UNROLL; ++u) *reinterpret_cast<U16x8*>(ob + off + u * step) = norm(v[u]);
     }
     for (; row < r1; row += R) {
       const int64_t off = (int64_t)row * C + c0;
-      *reinterpret_cast<U16x8*>(ob + off) = norm(*reinterpret_cast<const U16x8*>(xb + off));
+      Row8<X32> v;
+      v.load(x, xb + off);
+      *reinterpret_cast<U16x8*>(ob + off) = norm(v);
     }
   }
 }
@@ -565,25 +610,25 @@ k_gn_nhwc_apply(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gam
 #define LN_MAX_IT 4
 #define LN_ROWS_PER_BLOCK 4
 
-template <typename T>
+template <typename T, bool X32 = false>     // X32: x is the fp32 residual stream (round 6); the result stays 16-bit
 __global__ void __launch_bounds__(64 * LN_ROWS_PER_BLOCK)
-k_layernorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+k_layernorm(const void* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
             uint16_t* __restrict__ out, int64_t M, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
   const int VC = D >> 3;
-  const uint16_t* xr = x + row * (int64_t)D;
   float v[LN_MAX_IT][8];
   float s = 0.f;
 #pragma unroll
   for (int it = 0; it < LN_MAX_IT; ++it) {
     int vc = lane + it * 64;
     if (vc < VC) {
-      U16x8 u = *reinterpret_cast<const U16x8*>(xr + (vc << 3));
+      Row8<X32> u;
+      u.load(x, row * (int64_t)D + (vc << 3));
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[it][e] = T::to_f32(u.v[e]);
+        v[it][e] = X32 ? u.f32(e) : T::to_f32(u.h.v[e]);
         s += v[it][e];
       }
     }
@@ -625,18 +670,17 @@ k_layernorm(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma, 
 // ---- residual add + LayerNorm: sum = round16(a + b) (torch's 16-bit add), out = LayerNorm(sum) -------------------------
 // BasicTransformerBlock: `x = attn(norm(x)) + x` followed by the next `norm(x)`: one read of each addend, one write of
 // the new residual stream and one of its normalisation, instead of add (2r + 1w) + LayerNorm (1r + 1w).
-template <typename T>
+// S32 (round 6): b and sum_out are the fp32 residual stream -- sum = a + b in fp32, stored unrounded; a and the normalised output stay 16-bit
+template <typename T, bool S32 = false>
 __global__ void __launch_bounds__(64 * LN_ROWS_PER_BLOCK)
-k_add_layernorm(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, const uint16_t* __restrict__ gamma,
-                const uint16_t* __restrict__ beta, uint16_t* __restrict__ sum_out, uint16_t* __restrict__ out, int64_t M,
+k_add_layernorm(const uint16_t* __restrict__ a, const void* __restrict__ b, const uint16_t* __restrict__ gamma,
+                const uint16_t* __restrict__ beta, void* __restrict__ sum_out, uint16_t* __restrict__ out, int64_t M,
                 int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
   const int VC = D >> 3;
   const uint16_t* ar = a + row * (int64_t)D;
-  const uint16_t* br = b + row * (int64_t)D;
-  uint16_t* sr = sum_out + row * (int64_t)D;
   float v[LN_MAX_IT][8];
   float s = 0.f;
 #pragma unroll
@@ -644,15 +688,27 @@ k_add_layernorm(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, 
     int vc = lane + it * 64;
     if (vc < VC) {
       U16x8 ua = *reinterpret_cast<const U16x8*>(ar + (vc << 3));
-      U16x8 ub = *reinterpret_cast<const U16x8*>(br + (vc << 3));
-      U16x8 us;
+      Row8<S32> ub;
+      ub.load(b, row * (int64_t)D + (vc << 3));
+      if (S32) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        us.v[e] = T::from_f32(T::to_f32(ua.v[e]) + T::to_f32(ub.v[e]));
-        v[it][e] = T::to_f32(us.v[e]);
-        s += v[it][e];
+        for (int e = 0; e < 8; ++e) {
+          v[it][e] = T::to_f32(ua.v[e]) + ub.f32(e);
+          s += v[it][e];
+        }
+        float4* sp = reinterpret_cast<float4*>(reinterpret_cast<float*>(sum_out) + row * (int64_t)D + (vc << 3));
+        sp[0] = float4{v[it][0], v[it][1], v[it][2], v[it][3]};
+        sp[1] = float4{v[it][4], v[it][5], v[it][6], v[it][7]};
+      } else {
+        U16x8 us;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          us.v[e] = T::from_f32(T::to_f32(ua.v[e]) + T::to_f32(ub.h.v[e]));
+          v[it][e] = T::to_f32(us.v[e]);
+          s += v[it][e];
+        }
+        *reinterpret_cast<U16x8*>(reinterpret_cast<uint16_t*>(sum_out) + row * (int64_t)D + (vc << 3)) = us;
       }
-      *reinterpret_cast<U16x8*>(sr + (vc << 3)) = us;
     }
   }
 #pragma unroll
@@ -1063,12 +1119,12 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void*
   return done();
 }
 
-int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
-                      void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
-                      void* stream) {
+static int gn_nhwc_launch(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+                          void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu, bool x32,
+                          void* stream) {
   if (N == 0) return 0;
   // C/G >= 8: an 8-channel vector then touches at most two groups (what the partial-sum kernel bins into)
-  if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 || C > 8 * GNL_THREADS * GNL_MAXCOL ||
+  if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 || C > 8 * GNL_THREADS * GNL_MAXCOL || (x32 && (conv_bias || chan_bias)) ||
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
     return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -1079,20 +1135,26 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
   const int VC_ = C / 8;
   size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= pl.threads ? pl.threads / VC_ : 1);
   const int rows_per_block = pl.rows_per_block;
-#define GNL_RUN(T)                                                                                                     \
-  k_gn_nhwc_partial<T><<<grid1, pl.threads, lds, s>>>((const uint16_t*)x, (const uint16_t*)conv_bias,                 \
-                                                      (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
+#define GNL_RUN2(T, X32)                                                                                               \
+  k_gn_nhwc_partial<T, X32><<<grid1, pl.threads, lds, s>>>(x, (const uint16_t*)conv_bias,                              \
+                                                           (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
   k_gn_nhwc_finalize<<<N, GNL_THREADS, 0, s>>>(partial, stats, G, pl.nchunks, (double)HW * (C / G), eps);             \
   if (act_silu)                                                                                                        \
-    k_gn_nhwc_apply<T, true><<<grid1, pl.threads, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                  \
+    k_gn_nhwc_apply<T, true, X32><<<grid1, pl.threads, 0, s>>>(x, (const uint16_t*)gamma,                              \
                                                          (const uint16_t*)beta, (const uint16_t*)conv_bias,            \
                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW,     \
                                                          G, rows_per_block);                                           \
   else                                                                                                                 \
-    k_gn_nhwc_apply<T, false><<<grid1, pl.threads, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma,                 \
+    k_gn_nhwc_apply<T, false, X32><<<grid1, pl.threads, 0, s>>>(x, (const uint16_t*)gamma,                             \
                                                           (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
                                                           (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW,    \
                                                           G, rows_per_block);
+#define GNL_RUN(T)        \
+  if (x32) {              \
+    GNL_RUN2(T, true)     \
+  } else {                \
+    GNL_RUN2(T, false)    \
+  }
   if (dtype == ED_BF16) {
     GNL_RUN(BF16)
   } else if (dtype == ED_F16) {
@@ -1101,11 +1163,23 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
     return (int)hipErrorInvalidValue;
   }
 #undef GNL_RUN
+#undef GNL_RUN2
   return done();
 }
 
-int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
-                 void* stream) {
+int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+                      void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
+                      void* stream) {
+  return gn_nhwc_launch(x, gamma, beta, conv_bias, chan_bias, out, workspace, dtype, N, C, HW, G, eps, act_silu, false, stream);
+}
+
+int ed_groupnorm_nhwc_s32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N, int C,
+                          int HW, int G, float eps, int act_silu, void* stream) {
+  return gn_nhwc_launch(x, gamma, beta, nullptr, nullptr, out, workspace, dtype, N, C, HW, G, eps, act_silu, true, stream);
+}
+
+static int layernorm_launch(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
+                            bool x32, void* stream) {
   if (M == 0) return 0;
   if (D % 8 != 0 || D > 64 * 8 * LN_MAX_IT ||
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
@@ -1114,19 +1188,32 @@ int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, 
   if (blocks > 0x7fffffff) return (int)hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(64 * LN_ROWS_PER_BLOCK);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == ED_BF16)
-    k_layernorm<BF16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta,
-                                            (uint16_t*)out, M, D, eps);
-  else if (dtype == ED_F16)
-    k_layernorm<F16><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)gamma, (const uint16_t*)beta,
-                                           (uint16_t*)out, M, D, eps);
-  else
+#define LN_RUN(T, X32) k_layernorm<T, X32><<<grid, block, 0, s>>>(x, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)out, M, D, eps)
+  if (dtype == ED_BF16) {
+    if (x32) LN_RUN(BF16, true);
+    else LN_RUN(BF16, false);
+  } else if (dtype == ED_F16) {
+    if (x32) LN_RUN(F16, true);
+    else LN_RUN(F16, false);
+  } else {
     return (int)hipErrorInvalidValue;
+  }
+#undef LN_RUN
   return done();
 }
 
-int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
-                     int dtype, int64_t M, int D, float eps, void* stream) {
+int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
+                 void* stream) {
+  return layernorm_launch(x, gamma, beta, out, dtype, M, D, eps, false, stream);
+}
+
+int ed_layernorm_s32(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
+                     void* stream) {
+  return layernorm_launch(x, gamma, beta, out, dtype, M, D, eps, true, stream);
+}
+
+static int add_layernorm_launch(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
+                                int dtype, int64_t M, int D, float eps, bool s32, void* stream) {
   if (M == 0) return 0;
   if (D % 8 != 0 || D > 64 * 8 * LN_MAX_IT ||
       (((uintptr_t)a | (uintptr_t)b | (uintptr_t)sum_out | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
@@ -1135,15 +1222,30 @@ int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void
   if (blocks > 0x7fffffff) return (int)hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(64 * LN_ROWS_PER_BLOCK);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == ED_BF16)
-    k_add_layernorm<BF16><<<grid, block, 0, s>>>((const uint16_t*)a, (const uint16_t*)b, (const uint16_t*)gamma,
-                                                (const uint16_t*)beta, (uint16_t*)sum_out, (uint16_t*)out, M, D, eps);
-  else if (dtype == ED_F16)
-    k_add_layernorm<F16><<<grid, block, 0, s>>>((const uint16_t*)a, (const uint16_t*)b, (const uint16_t*)gamma,
-                                               (const uint16_t*)beta, (uint16_t*)sum_out, (uint16_t*)out, M, D, eps);
-  else
+#define ALN_RUN(T, S32)                                                                                                        \
+  k_add_layernorm<T, S32><<<grid, block, 0, s>>>((const uint16_t*)a, b, (const uint16_t*)gamma, (const uint16_t*)beta, sum_out, \
+                                                 (uint16_t*)out, M, D, eps)
+  if (dtype == ED_BF16) {
+    if (s32) ALN_RUN(BF16, true);
+    else ALN_RUN(BF16, false);
+  } else if (dtype == ED_F16) {
+    if (s32) ALN_RUN(F16, true);
+    else ALN_RUN(F16, false);
+  } else {
     return (int)hipErrorInvalidValue;
+  }
+#undef ALN_RUN
   return done();
+}
+
+int ed_add_layernorm(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
+                     int dtype, int64_t M, int D, float eps, void* stream) {
+  return add_layernorm_launch(a, b, gamma, beta, sum_out, out, dtype, M, D, eps, false, stream);
+}
+
+int ed_add_layernorm_s32(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
+                         int dtype, int64_t M, int D, float eps, void* stream) {
+  return add_layernorm_launch(a, b, gamma, beta, sum_out, out, dtype, M, D, eps, true, stream);
 }
 
 int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, const void* res_bias, void* out, int dtype,

@@ -91,6 +91,12 @@ def group_norm_act(norm, x, silu=False, tokens=False, chan_bias=None, conv_bias=
             x = x + conv_bias[None, :, None, None]
         if chan_bias is not None:
             x = x + chan_bias[:, :, None, None]
+        cpg32 = C // norm.num_groups
+        if (FUSED_KERNELS and x.is_cuda and C % 8 == 0 and cpg32 >= 8 and C <= 4096 and norm.num_groups <= 256
+                and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)):
+            from . import ops      # HIP: ed_groupnorm_nhwc_s32 (fp32 stream in, model dtype out; the 16-bit kernel's three launches)
+            y = ops.groupnorm_nhwc_s32(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
+            return y.permute(0, 2, 3, 1).reshape(N, H * W, C) if tokens else y
         w32, b32 = _f32_params(norm)
         y = F.group_norm(x, norm.num_groups, w32, b32, norm.eps)
         if silu:
@@ -264,6 +270,9 @@ def layer_norm(norm, x):
     """LayerNorm over the last dim.  HIP: ed_layernorm (one wave per row); torch otherwise."""
     D = x.shape[-1]
     if norm.elementwise_affine and _stream32(x, norm.weight.dtype):   # fp32 residual stream -> model dtype
+        if FUSED_LAYERNORM and FUSED_KERNELS and x.is_cuda and x.is_contiguous() and D % 8 == 0 and D <= 2048:
+            from . import ops
+            return ops.layernorm_s32(x, norm.weight, norm.bias, norm.eps)
         w32, b32 = _f32_params(norm)
         return F.layer_norm(x, (D,), w32, b32, norm.eps).to(norm.weight.dtype)
     if FUSED_LAYERNORM and _fusable(x) and D % 8 == 0 and D <= 2048 and norm.elementwise_affine:
@@ -279,6 +288,10 @@ def add_layer_norm(norm, a, b):
             and norm.elementwise_affine):
         from . import ops
         return ops.add_layernorm(a, b, norm.weight, norm.bias, norm.eps)
+    if (FUSED_ADD_LAYERNORM and FUSED_KERNELS and norm.elementwise_affine and _fusable(a) and _stream32(b, a.dtype) and b.is_cuda
+            and b.is_contiguous() and a.shape == b.shape and D % 8 == 0 and D <= 2048 and norm.weight.dtype == a.dtype):
+        from . import ops      # fp32 residual stream: 16-bit branch result + fp32 stream -> (fp32 stream, 16-bit LayerNorm)
+        return ops.add_layernorm_s32(a, b, norm.weight, norm.bias, norm.eps)
     s = a + b          # (fp32 residual stream: a 16-bit branch result + the fp32 stream -> fp32)
     return s, layer_norm(norm, s)
 

@@ -511,6 +511,53 @@ def add_layernorm(a, b, gamma, beta, eps):
     return s, out
 
 
+# ---- the fp32-residual-stream mode (models.UNet2DConditionModel.residual_fp32): the layers that read / write the stream ----------------
+def _stream_ok(x, w):
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and w.dtype in (torch.float16, torch.bfloat16)
+            and w.device == x.device)
+
+
+def layernorm_s32(x, gamma, beta, eps):
+    """x [..., D] contiguous fp32 (the residual stream) -> LayerNorm over D in gamma's 16-bit dtype (ed_layernorm_s32)."""
+    if not _stream_ok(x, gamma) or not x.is_contiguous():
+        _reject("layernorm_s32: x must be a contiguous fp32 tensor on the MI355X and gamma 16-bit; no CPU fallback")
+    D = x.shape[-1]
+    out = torch.empty(x.shape, dtype=gamma.dtype, device=x.device)
+    TIMER.note_work("ed_layernorm_s32", nbytes=x.numel() * 6.0)
+    _LAUNCH["device"] = x.device
+    _call("ed_layernorm_s32", x.data_ptr(), _dev(gamma, None, "gamma"), _dev(beta, gamma.dtype, "beta"), out.data_ptr(),
+          _DTYPE[gamma.dtype], x.numel() // D, D, float(eps), _stream())
+    return out
+
+
+def add_layernorm_s32(a, b, gamma, beta, eps):
+    """a [..., D] 16-bit (a branch result), b [..., D] fp32 (the residual stream) -> (a + b in fp32, LayerNorm(a + b) in a's dtype)."""
+    if not (_stream_ok(b, a) and a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and gamma.dtype == a.dtype):
+        _reject("add_layernorm_s32: a must be 16-bit and b fp32, same shape, contiguous, on the MI355X; no CPU fallback")
+    D = a.shape[-1]
+    s, out = torch.empty_like(b), torch.empty_like(a)
+    TIMER.note_work("ed_add_layernorm_s32", nbytes=a.numel() * 12.0)
+    _LAUNCH["device"] = a.device
+    _call("ed_add_layernorm_s32", a.data_ptr(), b.data_ptr(), _dev(gamma, None, "gamma"), _dev(beta, a.dtype, "beta"), s.data_ptr(),
+          out.data_ptr(), _DTYPE[a.dtype], a.numel() // D, D, float(eps), _stream())
+    return s, out
+
+
+def groupnorm_nhwc_s32(x, gamma, beta, groups, eps, silu=False):
+    """x [N,C,H,W] fp32 in channels_last memory (the residual stream) -> GroupNorm(+SiLU) in gamma's 16-bit dtype, channels_last."""
+    if not _stream_ok(x, gamma) or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        _reject("groupnorm_nhwc_s32: x must be an fp32 channels_last [N,C,H,W] tensor on the MI355X and gamma 16-bit; no CPU fallback")
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H, W), dtype=gamma.dtype, device=x.device, memory_format=torch.channels_last)
+    nbytes = _hip.lib().ed_groupnorm_nhwc_workspace(N, C, H * W, groups)
+    ws = torch.empty(max(4, nbytes // 4), dtype=torch.float32, device=x.device)
+    TIMER.note_work("ed_groupnorm_nhwc_s32", nbytes=x.numel() * 10.0)
+    _LAUNCH["device"] = x.device
+    _call("ed_groupnorm_nhwc_s32", x.data_ptr(), _dev(gamma, None, "gamma"), _dev(beta, gamma.dtype, "beta"), out.data_ptr(),
+          ws.data_ptr(), _DTYPE[gamma.dtype], N, C, H * W, groups, float(eps), int(silu), _stream())
+    return out
+
+
 def bias_residual_add(h, h_bias, res, res_bias=None):
     """round16(res (+ res_bias[c])) + round16(h + h_bias[c]) for 16-bit [N,C,H,W] tensors that are both NCHW-contiguous
     or both channels_last (ResnetBlock2D's closing add); the result has the same memory format."""

@@ -221,6 +221,20 @@ int ed_bias_residual_add(const void* h, const void* h_bias, const void* res, con
  */
 int ed_layernorm(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
                  void* stream);
+/*
+ * ---- the fp32-residual-stream mode of the UNet (round 6; models.UNet2DConditionModel.residual_fp32) -----------------------------
+ * The tolerance mode for configurations whose plain-fp16 latent ends outside north_star's 1e-3 (cfg2): the tensor that persists from
+ * block to block is fp32, every branch computes in the 16-bit model dtype.  These entry points are the memory-bound layers that READ
+ * the stream: same arithmetic as their 16-bit namesakes, x (ed_layernorm_s32, ed_groupnorm_nhwc_s32) or b and sum_out
+ * (ed_add_layernorm_s32: sum_out = a + b in fp32, unrounded) are fp32, everything else -- gamma, beta, a, out -- has `dtype`.
+ * ed_groupnorm_nhwc_s32 takes no folded biases; workspace: ed_groupnorm_nhwc_workspace.  Same shape limits as the namesakes.
+ */
+int ed_layernorm_s32(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,
+                     void* stream);
+int ed_add_layernorm_s32(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* out,
+                         int dtype, int64_t M, int D, float eps, void* stream);
+int ed_groupnorm_nhwc_s32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N, int C,
+                          int HW, int G, float eps, int act_silu, void* stream);
 
 /*
  * ed_add_layernorm -- residual add + LayerNorm in one pass (BasicTransformerBlock: `x = attn(norm(x)) + x` and the

@@ -158,7 +158,7 @@ def test_text_kv_computed_once_per_image_follows_the_prompt():
 # Bars are ABSOLUTE: fp32 product < 1e-3 at every checkpoint (BASELINE.json's tolerance; measured ~1e-5), fp16 product at the end of the
 # schedule <= LONG_FP16_BAR = 1.2 x what the first run measured (profiles/r6_s1_long_schedule_parity.json), i.e. a regression of the
 # 16-bit path by 20 % fails here by name instead of surfacing as a drifting number in a bench line.
-LONG_FP16_BAR = 6.0e-3      # provisional until the first measurement (the 2-3-step loops sit at 4.6-5.5e-3)
+LONG_FP16_BAR = 1.64e-3     # 1.2 x 1.366e-3 (profiles/r6_s2_long_schedule_parity.json: 1.06e-3 at step 2, flat at 1.36-1.37e-3 from step 12 on)
 
 
 def test_full_schedule_fp16_vs_reference_latent(golden_dir):

@@ -144,6 +144,59 @@ def test_groupnorm_channels_last_at_the_unet_shapes_many_chunks(N, C, H, W):
         assert torch.equal(got, ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=True))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,D", [(300, 320), (77, 640), (1024, 1280), (5, 2048)])
+def test_layernorm_and_add_layernorm_on_the_fp32_residual_stream(dtype, M, D):
+    """ed_layernorm_s32 / ed_add_layernorm_s32 (round 6, the fp32-residual-stream tolerance mode): the stream is fp32, the branch result
+    and the normalised output 16-bit.  Against fp32 torch: the sum is EXACT (a widened + b), the LayerNorm within one 16-bit rounding."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator().manual_seed(M + D)
+    x = (torch.randn(M, D, generator=g) * 3 + 0.5).to(DEV)
+    a = torch.randn(M, D, generator=g).to(DEV, dtype)
+    w = (1 + 0.2 * torch.randn(D, generator=g)).to(DEV, dtype)
+    b = (0.1 * torch.randn(D, generator=g)).to(DEV, dtype)
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    got = ops.layernorm_s32(x, w, b, 1e-5)
+    ref = F.layer_norm(x, (D,), w.float(), b.float(), 1e-5)
+    assert got.dtype == dtype
+    err = (got.float() - ref).abs()
+    assert bool((err <= 1.0 * ulp * ref.abs() + 2 * ulp).all()), float(err.max())
+    s, ln = ops.add_layernorm_s32(a, x, w, b, 1e-5)
+    assert s.dtype == torch.float32 and ln.dtype == dtype
+    assert torch.equal(s, a.float() + x)
+    ref = F.layer_norm(a.float() + x, (D,), w.float(), b.float(), 1e-5)
+    err = (ln.float() - ref).abs()
+    assert bool((err <= 1.0 * ulp * ref.abs() + 2 * ulp).all()), float(err.max())
+    assert torch.equal(ln, ops.layernorm_s32(s, w, b, 1e-5))
+    s2, ln2 = ops.add_layernorm_s32(a, x, w, b, 1e-5)
+    assert torch.equal(s2, s) and torch.equal(ln2, ln)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(3, 320, 32, 32), (2, 1280, 8, 8), (1, 960, 64, 64), (1, 2560, 8, 8), (6, 640, 64, 64)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_channels_last_on_the_fp32_residual_stream(dtype, N, C, H, W, silu):
+    """ed_groupnorm_nhwc_s32: fp32 channels-last stream in, GroupNorm (+SiLU) in the model dtype out (the operand of the next GEMM)."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator().manual_seed(N * C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.7 + 0.3).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV, dtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV, dtype)
+    got = ops.groupnorm_nhwc_s32(x, w, b, 32, 1e-5, silu=silu)
+    assert got.dtype == dtype and got.shape == x.shape and got.is_contiguous(memory_format=torch.channels_last)
+    ref = F.group_norm(x, 32, w.float(), b.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    err = (got.float() - ref).abs()
+    assert bool((err <= 2.0 * ulp * ref.abs() + 4 * ulp).all()), float(err.max())
+    assert torch.equal(got, ops.groupnorm_nhwc_s32(x, w, b, 32, 1e-5, silu=silu))
+    # the 16-bit kernel on the rounded stream differs from this one only by that input rounding
+    x16 = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    near = ops.groupnorm_nhwc(x16, w, b, 32, 1e-5, silu=silu)
+    assert float((near.float() - got.float()).norm() / got.float().norm()) < 8 * ulp
+
+
 def test_unet_channels_last_path_close():
     """The whole (small) UNet with channels-last activations + NHWC GroupNorm vs the default NCHW path."""
     from elasticdiffusion_official_amd import models as M
