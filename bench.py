@@ -268,9 +268,10 @@ def main():
                          "2 timed images (the driver's command), off otherwise")
     ap.add_argument("--fp32-leg-seeds", type=int, default=1,
                     help="how many of the last timed images (one seed each) the fp32 leg repeats; 1 (default) keeps the leg at ~2 min")
-    ap.add_argument("--residual-fp32", action="store_true",
-                    help="tolerance mode: the UNet's residual stream in fp32 under the 16-bit branches (ElasticDiffusion(residual_fp32=True)); "
-                         "reported in config.precision_mode -- never the default headline")
+    ap.add_argument("--residual-fp32", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
+                    help="the UNet's residual stream in fp32 under the 16-bit branches (ElasticDiffusion(residual_fp32=...)): the mode that meets "
+                         "north_star's 1e-3 where plain fp16 does not.  auto = the product's default, by measurement per model family (on for "
+                         "SD 1.x / 2.x, off for SDXL); reported in config.precision_mode")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: initialise RCCL with one rank and send every sharded batch through the all-gather path "
                          "(what a 1-GPU box can exercise of the multi-GPU exchange)")
@@ -341,7 +342,7 @@ def main():
         """the workload's pipeline class over process group ``group`` (False = unsharded)"""
         common = dict(view_batch_size=wl["vbs"], model_dtype=model_dtype or dtype, process_group=group,
                       cache_backgrounds=args.cache_backgrounds,
-                      residual_fp32=bool(args.residual_fp32 and (model_dtype or dtype) != torch.float32), **inj)
+                      residual_fp32={"auto": None, "on": True, "off": False}[args.residual_fp32], **inj)
         if cn_scale is not None:
             from elasticdiffusion_official_amd import ElasticDiffusionControlNet
             return ElasticDiffusionControlNet(dev, wl["sd"], "depth", **common)
@@ -566,8 +567,8 @@ def main():
                                        + ("; each finished latent is decoded once, by one rank of its group" if m > 1 else "")),
                        "shard_group": g, "images_in_flight": m,
                        "background_cache": bool(args.cache_backgrounds),
-                       "precision_mode": ("16-bit branches, fp32 residual stream (--residual-fp32)" if args.residual_fp32 and dtype != torch.float32
-                                          else "all " + args.dtype),
+                       "precision_mode": (f"{args.dtype} branches, fp32 residual stream (--residual-fp32 {args.residual_fp32})"
+                                          if getattr(pipe, "residual_fp32", False) else "all " + args.dtype),
                        "controlnet_conditioning_scale": cn_scale,
                        "weights": f"random-init {fam} architecture" + (" + ControlNet" if cn_scale is not None else "") + ", seed 0",
                        "vae_dtype": "fp32"},

@@ -579,7 +579,9 @@ k_gn_nhwc_apply(const void* __restrict__ x, const uint16_t* __restrict__ gamma, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xin = X32 ? v.f32(e) : biased<T>(v.h.v[e], kb[e], has_kb, cb[e], has_cb);
-        const float y = T::to_f32(T::from_f32(fmaf(a[e], xin, b[e])));
+        // 16-bit module: the normalised value is rounded before SiLU, as torch's two kernels round it; on the fp32 stream (the tolerance
+        // mode) nothing asks for that intermediate rounding: one rounding, of the final result
+        const float y = X32 ? fmaf(a[e], xin, b[e]) : T::to_f32(T::from_f32(fmaf(a[e], xin, b[e])));
         o.v[e] = ACT ? T::from_f32(silu_fast(y)) : T::from_f32(y);
       }
       return o;
