@@ -37,6 +37,7 @@
 //     LDS reads and DMAs the other owns the matrix pipe (the two share every SIMD).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "elastic_hip.h"
 
@@ -379,6 +380,40 @@ __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Fra
   ED_BARRIER();
 }
 
+// ROWS (round 6): a 128-row tile -- each wave row runs its m-half 0 only (64 rows), both column halves -- for grids that leave the chip
+// under-filled with 256-row tiles: the batch-6 forward's 32 x 32 convolutions are 120 tiles on 256 CUs (240 half-height ones fill 94 % of one
+// round at ~0.55 of a tile's time), a 3-row per-rank forward of the multi-GPU layout 60.  Four barrier intervals per K tile, the structure of
+// tile_phases_half with the roles of "x m-half 1" and "W gate rows" exchanged (so the LDS hazard analysis is that one's; replay:
+// tools/emulate_gemm_kernel.py --rows):
+//   R1  W value rows + x m-half 0 (12 fragment reads); W GATE rows of tile + 1 -> the other buffer (its copy was last read in the previous R2)
+//   M1  16 MFMAs (m half 0 x value)
+//   R2  W gate rows (4 reads); W value rows and x m-half 0 of tile + 2 -> this buffer (both last read in R1, by either wave row one interval
+//       ago); vmcnt(4): all of tile + 1 has landed, those two half tiles stay in flight
+//   M2  16 MFMAs (m half 0 x gate)
+template <class T, int BUFI, bool CONV>
+__device__ __forceinline__ void tile_phases_rows(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], bool s1, bool s2, KPos p1,
+                                                 KPos p2) {
+  read_w<T, BUFI, 0>(lds, c, f);
+  read_x<T, BUFI>(lds, c, f, 0);
+  if (s1) stage_w<BUFI ^ 1>(lds, c, p1.w, 1);
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 0, 0>(acc, f);
+  ED_BARRIER();
+  read_w<T, BUFI, 1>(lds, c, f);
+  if (s2) {
+    stage_w<BUFI>(lds, c, p2.w, 0);
+    stage_x<BUFI, CONV>(lds, c, p2, 0);
+    ED_WAIT_VM(4);
+  } else {
+    ED_WAIT_VM(0);
+  }
+  ED_WAIT_LGKM(0);
+  ED_BARRIER();
+  mma16<T, 0, 1>(acc, f);
+  ED_BARRIER();
+}
+
 // EPI 0: GEGLU -- W is [2 I, K], the two 128-row halves of the tile are value rows n0.. and gate rows I + n0.., out is [M, I]
 // EPI 1: plain projection + bias -- W is [I, K] (I = output columns), the halves are rows n0.. and n0 + 128.., out is [M, I];
 //        the same main loop, kept so that the schedule can be timed against hipBLASLt on every projection of the block
@@ -394,7 +429,8 @@ __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Fra
 // fp32 data ([I], [M, I], [M, I]); out = out_scale * acc + bias + residual with NO rounding to 16 bits -- the accumulators already are
 // the fp32 result; out_scale (a power of two) undoes the pre-scaling of the split weights.  row_bias is not used.
 // TWO: the long-K loop (tile_phases_two) instead of the 8-phase one -- a separate instantiation (both loops in one kernel made hipcc spill).
-template <class T, int EPI, bool CONV, bool ADD = true, bool OUT32 = false, bool TWO = false>
+// ROWS: 128-row tiles (tile_phases_rows) -- a separate instantiation the launcher picks for under-filled grids (launch: rows_mode_pays).
+template <class T, int EPI, bool CONV, bool ADD = true, bool OUT32 = false, bool TWO = false, bool ROWS = false>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
               const uint16_t* __restrict__ row_bias, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int M,
@@ -411,7 +447,10 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   const int n_blocks_m = n_blocks / n_blocks_n;
   const int per_group = 8 * n_blocks_n, grp = tid / per_group, first = grp * 8;
   const int rows_here = n_blocks_m - first < 8 ? n_blocks_m - first : 8;
-  const int m0 = (first + (tid % per_group) % rows_here) * BM;
+  constexpr int TBM = ROWS ? BM / 2 : BM;            // rows per tile
+  constexpr int WROWS = TBM / 2;                     // rows per wave row
+  constexpr int NMB = WROWS / 16;                    // 16-row blocks per wave row
+  const int m0 = (first + (tid % per_group) % rows_here) * TBM;
   const int n0 = ((tid % per_group) / rows_here) * (EPI == 0 ? BN : 2 * BN);
   const int gap = EPI == 0 ? I : BN;                 // W rows (= output columns for EPI 1) from the first half to the second
 
@@ -426,7 +465,7 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   const int x_row_bytes = CONV ? row_bytes / 9 : row_bytes;      // CONV: one pixel's Cin values
   c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * x_row_bytes), 0x00020000);
   c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)(EPI == 0 ? 2 : 1) * I * row_bytes), 0x00020000);
-  const int xrow0 = m0 + ((c.wave & 3) + 8 * (c.wave >> 2)) * 16 + srow;   // the lane's row of m half 0; m half 1 is 64 rows on
+  const int xrow0 = m0 + ((c.wave & 3) + (ROWS ? 4 : 8) * (c.wave >> 2)) * 16 + srow;   // the lane's row of m half 0; m half 1 is 64 rows on (ROWS: none)
   c.x_voff[0] = xrow0 * x_row_bytes + skb;
   c.x_voff[1] = c.x_voff[0] + 64 * x_row_bytes;
   c.img_w = img_w;
@@ -481,8 +520,32 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   const KPos p0 = {0, 0, 0, 0};
   KPos pa = k_next<CONV>(p0, c.cpt);      // position of tile t + 1
   KPos pb = k_next<CONV>(pa, c.cpt);      // position of tile t + 2
-  const bool half = EPI == 1 && n0 + BN >= I;     // wave-uniform: nothing of this tile's second half is inside the output (tile_phases_half)
-  if (half) {
+  const bool half = !ROWS && EPI == 1 && n0 + BN >= I;     // wave-uniform: nothing of this tile's second half is inside the output (tile_phases_half)
+  if (ROWS) {
+    stage_w<0>(lds, c, 0, 0);
+    stage_x<0, CONV>(lds, c, p0, 0);
+    stage_w<0>(lds, c, 0, 1);
+    if (nt > 1) {
+      stage_w<1>(lds, c, pa.w, 0);
+      stage_x<1, CONV>(lds, c, pa, 0);
+      ED_WAIT_VM(4);              // all of tile 0 (6 DMAs); tile 1's two half tiles stay in flight
+    } else {
+      ED_WAIT_VM(0);
+    }
+    ED_BARRIER();
+    if (wrow == 1) ED_BARRIER();
+    int tr = 0;
+    for (; tr + 1 < nt; tr += 2) {
+      tile_phases_rows<T, 0, CONV>(lds, c, f, acc, true, tr + 2 < nt, pa, pb);
+      pa = pb;
+      pb = k_next<CONV>(pb, c.cpt);
+      tile_phases_rows<T, 1, CONV>(lds, c, f, acc, tr + 2 < nt, tr + 3 < nt, pa, pb);
+      pa = pb;
+      pb = k_next<CONV>(pb, c.cpt);
+    }
+    if (tr < nt) tile_phases_rows<T, 0, CONV>(lds, c, f, acc, false, false, pa, pb);
+    if (wrow == 0) ED_BARRIER();
+  } else if (half) {
     stage_w<0>(lds, c, 0, 0);
     stage_x<0, CONV>(lds, c, p0, 0);
     stage_x<0, CONV>(lds, c, p0, 1);
@@ -579,8 +642,8 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
       }
     }
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-      const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
+    for (int mb = 0; mb < NMB; ++mb) {
+      const int m = m0 + WROWS * wrow + 16 * mb + (lane & 15);
       if (m >= M) continue;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {      // value half / second ("gate") half of the 256 columns
@@ -604,8 +667,8 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
     bg[e >> 2][e & 3] = T::to_f32((uint16_t)(bias_g[e >> 1] >> (16 * (e & 1))));
   }
 #pragma unroll
-  for (int mb = 0; mb < 8; ++mb) {
-    const int m = m0 + 128 * wrow + 16 * mb + (lane & 15);
+  for (int mb = 0; mb < NMB; ++mb) {
+    const int m = m0 + WROWS * wrow + 16 * mb + (lane & 15);
     if (EPI == 0) {
       uint32_t pk[4];
 #pragma unroll
@@ -805,6 +868,20 @@ k_geglu_persist(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, 
 
 }  // namespace
 
+// CUs of the current device rounded down to a multiple of 8 (one 128-KiB-LDS workgroup per CU; cached per device)
+static int gemm_cus() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 0;
+    cus[dev] = n / 8 * 8;
+  }
+  return cus[dev];
+}
+constexpr double ROWS_TILE_COST = 0.56;   // time of a 128-row tile relative to a 256-row one (profiles/r6_s4_gemm_rows_mode.jsonl)
+
 // C ABI (include/elastic_hip.h).  Returns 0, a hipError_t, or hipErrorInvalidValue for a shape the kernel does not take.
 template <int EPI, bool CONV, bool OUT32 = false>
 static int launch(const void* x, const void* w, const void* bias, const void* row_bias, const void* residual, void* out, int dtype,
@@ -818,24 +895,44 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   if (M * (int64_t)(CONV ? K / 9 : K) * 2 >= 0x7ffffff0ll || (int64_t)(EPI == 0 ? 2 : 1) * I * K * 2 >= 0x7ffffff0ll) return bad;   // 32-bit buffer offsets
   if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)row_bias | (uintptr_t)residual) & 15u)) return bad;
   const int nbn = EPI == 0 ? I / BN : (I + 2 * BN - 1) / (2 * BN);
-  const int64_t nb = ((M + BM - 1) / BM) * nbn;
-  if (nb >= (1ll << 31) || M >= (1ll << 31)) return bad;
+  const int64_t nb256 = ((M + BM - 1) / BM) * nbn, nb128 = ((M + BM / 2 - 1) / (BM / 2)) * nbn;
+  if (nb128 >= (1ll << 31) || M >= (1ll << 31)) return bad;
   hipStream_t s = (hipStream_t)stream;
   const bool add = EPI == 1 && (row_bias || residual);
   const bool two = CONV && K / BK >= TWO_MIN_TILES;     // the long-K loop: convolutions only (measured negative on the plain projections)
-#define ED_LAUNCH1(TT, ADD_, TWO_)                                                                                                   \
-  k_gemm_8phase<TT, EPI, CONV, ADD_, OUT32, TWO_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, \
+  // 128-row tiles (ROWS) where they finish sooner: one workgroup per CU, so a grid runs in rounds of `cus` tiles; a half-height tile costs
+  // ROWS_TILE_COST of a full one (W staged and read for half the rows).  120 full tiles (the batch-6 forward's 32 x 32 convolutions):
+  // 1 round vs 0.56; 400: 2 rounds vs 4 x 0.56 -- stays.  ED_GEMM_ROWS=0 / 1 forces it off / on (measurement only).
+  bool rows = false;
+  if (!OUT32 && EPI == 1) {
+    const int cus = gemm_cus();
+    const double r256 = (double)((nb256 + cus - 1) / cus), r128 = (double)((nb128 + cus - 1) / cus) * ROWS_TILE_COST;
+    rows = cus > 0 && r128 < r256 - 1e-9;
+    if (const char* e = getenv("ED_GEMM_ROWS")) rows = e[0] == '1' ? true : (e[0] == '0' ? false : rows);
+  }
+  const int64_t nb = rows ? nb128 : nb256;
+#define ED_LAUNCH1(TT, ADD_, TWO_, ROWS_)                                                                                            \
+  k_gemm_8phase<TT, EPI, CONV, ADD_, OUT32, TWO_, ROWS_><<<(int)nb, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, \
                                                              (const uint16_t*)row_bias, (const uint16_t*)residual, (uint16_t*)out,  \
                                                              (int)M, K, I, nbn, (int)nb, img_h, img_w, rows_per_sample > 0 ? rows_per_sample : 1, out_scale, \
                                                              act_absmax)
-#define ED_LAUNCH(TT, ADD_)                          \
-  do {                                               \
-    if constexpr (CONV) {                            \
-      if (two) ED_LAUNCH1(TT, ADD_, true);           \
-      else ED_LAUNCH1(TT, ADD_, false);              \
-    } else {                                         \
-      ED_LAUNCH1(TT, ADD_, false);                   \
-    }                                                \
+#define ED_LAUNCH(TT, ADD_)                                   \
+  do {                                                        \
+    if constexpr (OUT32 || EPI == 0) {                        \
+      if constexpr (CONV) {                                   \
+        if (two) ED_LAUNCH1(TT, ADD_, true, false);           \
+        else ED_LAUNCH1(TT, ADD_, false, false);              \
+      } else {                                                \
+        ED_LAUNCH1(TT, ADD_, false, false);                   \
+      }                                                       \
+    } else if (rows) {                                        \
+      ED_LAUNCH1(TT, ADD_, false, true);                      \
+    } else if constexpr (CONV) {                              \
+      if (two) ED_LAUNCH1(TT, ADD_, true, false);             \
+      else ED_LAUNCH1(TT, ADD_, false, false);                \
+    } else {                                                  \
+      ED_LAUNCH1(TT, ADD_, false, false);                     \
+    }                                                         \
   } while (0)
   if constexpr (OUT32) {       // split-fp16 operands only (bf16's 8 significand bits would need three terms per operand)
     if (dtype != ED_F16 || row_bias) return bad;
@@ -869,15 +966,9 @@ int ed_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int
   const int64_t nb = ((M + BM - 1) / BM) * nbn;
   if (nb >= (1ll << 31) || M >= (1ll << 31)) return bad;
   // one workgroup per CU (128 KiB of LDS each); a multiple of 8 keeps a workgroup on its XCD for all of its tiles
-  static int cus[16] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return (int)hipErrorInvalidDevice;
-    cus[dev] = n / 8 * 8;
-  }
-  const int grid = nb < cus[dev] ? (int)nb : cus[dev];
+  const int ncu = gemm_cus();
+  if (ncu <= 0) return (int)hipErrorInvalidDevice;
+  const int grid = nb < ncu ? (int)nb : ncu;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == ED_BF16)
     k_geglu_persist<BF><<<grid, 512, 0, s>>>((const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, (int)M, K, I, nbn, (int)nb);

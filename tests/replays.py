@@ -1,5 +1,5 @@
 """The lane-level CPU replays (tools/emulate_*.py) as ONE pool of background subprocesses: the first test that asks for a result starts
-all of them at once (13 independent single-threaded numpy scripts, ~170 s of CPU work back to back, ~35 s side by side on the 8-core
+all of them at once (15 independent single-threaded numpy scripts, ~170 s of CPU work back to back, ~35 s side by side on the 8-core
 builder container), every later test only collects its own.  Each job has a deadline and is killed on expiry (tests/procs.py's rule:
 a hang is a named failure).  VERDICT r5 item 8: the CPU suite has to stay a few-minute check."""
 import os
@@ -24,6 +24,8 @@ JOBS = {
     "sched_bad_early_b": ("emulate_gemm_kernel.py", "--sched", "bad_early_b"),
     "half": ("emulate_gemm_kernel.py", "--half"),
     "break_half_raw": ("emulate_gemm_kernel.py", "--break", "half_raw"),
+    "rows": ("emulate_gemm_kernel.py", "--rows"),
+    "break_rows_raw": ("emulate_gemm_kernel.py", "--break", "rows_raw"),
     "flash_attention": ("emulate_flash_attention.py",),
 }
 _RUNNING = {}

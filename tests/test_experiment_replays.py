@@ -29,6 +29,13 @@ def test_half_tile_mode_replay_and_its_broken_variant():
     assert bad.returncode == 0 and "caught the deliberately broken schedule" in bad.stdout, bad.stdout + bad.stderr
 
 
+def test_128_row_tile_mode_replay_and_its_broken_variant():
+    ok = _run("rows")                 # round 6: a 128-row tile, each wave row runs its m-half 0 only (tile_phases_rows)
+    assert ok.returncode == 0 and "WRONG" not in ok.stdout and ok.stdout.count("exact") >= 22, ok.stdout + ok.stderr
+    bad = _run("break_rows_raw")
+    assert bad.returncode == 0 and "caught the deliberately broken schedule" in bad.stdout, bad.stdout + bad.stderr
+
+
 def test_attention_index_math_including_the_16x16x32_layout():
     ok = _run("flash_attention")
     assert ok.returncode == 0 and "index math OK" in ok.stdout and ok.stdout.count("16x16x32 experiment") == 3, ok.stdout + ok.stderr

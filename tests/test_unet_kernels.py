@@ -664,9 +664,17 @@ def test_geglu_gemm(dtype, M, K, I, any_grid):
     assert float((nob.float() - y0[:, :I] * F.gelu(y0[:, I:])).abs().max()) < 8 * ulp
 
 
+@pytest.fixture(params=["0", "1"], ids=["tiles256", "tiles128"])
+def tile_rows(request, monkeypatch):
+    """round 6: the launcher picks 128-row tiles (tile_phases_rows) for under-filled grids -- which every small test shape is -- so the
+    GEMM tests pin the mode (ED_GEMM_ROWS is read at every launch) and run BOTH loops on every shape"""
+    monkeypatch.setenv("ED_GEMM_ROWS", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,K,N", [(256, 64, 256), (300, 128, 200), (1000, 640, 1920), (4099, 640, 640), (2000, 2560, 640), (513, 320, 8)])
-def test_linear_hip(dtype, M, K, N, any_grid):
+def test_linear_hip(dtype, M, K, N, any_grid, tile_rows):
     """ed_linear (+bias, +residual) vs fp32: a single rounding of the fp32 result; ragged M and ragged / partial column blocks."""
     from elasticdiffusion_official_amd import ops
     g = torch.Generator().manual_seed(M + N)
@@ -691,7 +699,7 @@ def test_linear_hip(dtype, M, K, N, any_grid):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,Cin,N", [(2, 12, 20, 64, 200), (3, 16, 16, 128, 320), (1, 32, 32, 320, 320), (2, 8, 8, 1280, 640), (5, 7, 9, 192, 72)])
-def test_conv3x3_nhwc(dtype, B, H, W, Cin, N, any_grid):
+def test_conv3x3_nhwc(dtype, B, H, W, Cin, N, any_grid, tile_rows):
     """ed_conv3x3_nhwc vs F.conv2d in fp32 (+ bias, + per-sample channel bias, + residual): image borders, batch seams inside a
     256-row tile (B H W not a multiple of 256), 1..20 K tiles per tap, partial column blocks; bit-identical over launches."""
     from elasticdiffusion_official_amd import ops
@@ -712,6 +720,31 @@ def test_conv3x3_nhwc(dtype, B, H, W, Cin, N, any_grid):
         assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all()), float((got.float() - ref).abs().max())
         for _ in range(4):
             assert torch.equal(ops.conv3x3_nhwc(x, w, bias, sbias, res), got)
+
+
+def test_gemm_tile_height_is_chosen_by_round_count_and_both_heights_agree(monkeypatch, any_grid):
+    """The launcher's own choice (no ED_GEMM_ROWS): 120 full tiles on 256 CUs (the batch-6 forward's 32 x 32 convolutions) run as 240
+    128-row tiles.  Whatever it picks, the two tile heights compute the same sums in the same order per output element: bit-identical."""
+    from elasticdiffusion_official_amd import ops
+    cl = torch.channels_last
+    g = torch.Generator().manual_seed(7)
+    x = _asym((6, 1280, 32, 32), g).to(DEV, torch.float16).contiguous(memory_format=cl)
+    w = _asym((1280, 1280, 3, 3), g, (9 * 1280) ** -0.5).to(DEV, torch.float16).contiguous(memory_format=cl)
+    b = _asym((1280,), g).to(DEV, torch.float16)
+    monkeypatch.delenv("ED_GEMM_ROWS", raising=False)
+    auto = ops.conv3x3_nhwc(x, w, b)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ED_GEMM_ROWS", mode)
+        outs[mode] = ops.conv3x3_nhwc(x, w, b)
+    assert torch.equal(outs["0"], outs["1"]) and torch.equal(auto, outs["1"])
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    assert bool(((auto.float() - ref).abs() <= 2.0 ** -11 * ref.abs() + 1e-4).all())
+    xl, wl = _asym((3072, 1280), g).to(DEV, torch.float16), _asym((1280, 1280), g, 1280 ** -0.5).to(DEV, torch.float16)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ED_GEMM_ROWS", mode)
+        outs[mode] = ops.linear(xl, wl, b)
+    assert torch.equal(outs["0"], outs["1"])
 
 
 def test_gemm_wrappers_refuse_what_the_kernel_does_not_take():

@@ -69,7 +69,7 @@ class Wave:
         srow, skb = ps >> 6, ps & 63
         rb = blk.K * 2
         xrb = rb // 9 if blk.conv else rb                   # CONV: one pixel's Cin values
-        xrow0 = blk.m0 + ((wave & 3) + 8 * (wave >> 2)) * 16 + srow
+        xrow0 = blk.m0 + ((wave & 3) + (4 if getattr(blk, "rows_mode", False) else 8) * (wave >> 2)) * 16 + srow
         x0 = xrow0 * xrb + skb
         self.x_voff = [x0, x0 + 64 * xrb]
         self.px_mask = [np.zeros(64, np.int64), np.zeros(64, np.int64)]
@@ -97,7 +97,8 @@ class Wave:
 
 class Block:
     def __init__(self, x, w, bias, M, K, I, m0, n0, mode, breakage=None, epi=0, conv=None, row_bias=None, residual=None,
-                 rows_per_sample=1):
+                 rows_per_sample=1, rows_mode=False):
+        self.rows_mode = rows_mode                      # round 6: 128-row tile, each wave row runs its m-half 0 only (tile_phases_rows)
         self.x, self.w, self.bias, self.M, self.K, self.I, self.m0, self.n0 = x, w, bias, M, K, I, m0, n0
         # round 4 epilogue addends of the plain projection / convolution: row_bias [M / rows_per_sample, I] (the time embedding),
         # residual [M, I]; the kernel reads 8 consecutive columns (16 bytes) per (lane, 16-row block, half) of each
@@ -381,6 +382,20 @@ class Block:
             lambda: self.mma16(wv, 1, 0),
         ]
 
+    def tile_segments_rows(self, wv, bufi, tile, s1, s2):
+        """gemm_kernels.hip's tile_phases_rows (round 6): a 128-row tile, m-half 0 only, both column halves -- tile_phases_half with the roles
+        of "x m-half 1" and "W gate rows" exchanged"""
+        return [
+            lambda: (self.read_w(wv, bufi, 0), self.read_x(wv, bufi, 0), self.stage_w(wv, bufi ^ 1, tile + 1, 1) if s1 else None,
+                     self.wait_lgkm(wv, 0)),
+            lambda: self.mma16(wv, 0, 0),
+            lambda: (self.read_w(wv, bufi, 1),
+                     (self.stage_w(wv, bufi, tile + 2, 0), self.stage_x(wv, bufi, tile + 2, 0)) if s2 else None,
+                     # BROKEN ON PURPOSE with 6 ("rows_raw"): the W gate rows of tile + 1 may not have landed when the tile ends
+                     self.wait_vm(wv, (6 if self.breakage == "rows_raw" else 4) if s2 else 0), self.wait_lgkm(wv, 0)),
+            lambda: self.mma16(wv, 0, 1),
+        ]
+
     def retarget(self, wv, m0, n0):
         """tools/gemm_persist: the workgroup moves on to its next tile -- the addresses `setup()` recomputes, a fresh accumulator."""
         self.m0, self.n0 = m0, n0
@@ -449,6 +464,30 @@ class Block:
     def program(self, wv):
         nt = self.K // BK
         segs = []
+        if self.rows_mode:
+            def prologue_rows():
+                self.stage_w(wv, 0, 0, 0)
+                self.stage_x(wv, 0, 0, 0)
+                self.stage_w(wv, 0, 0, 1)
+                if nt > 1:
+                    self.stage_w(wv, 1, 1, 0)
+                    self.stage_x(wv, 1, 1, 0)
+                    self.wait_vm(wv, 4)
+                else:
+                    self.wait_vm(wv, 0)
+            segs.append(prologue_rows)
+            if wv.wrow == 1:
+                segs.append(lambda: None)
+            t = 0
+            while t + 1 < nt:
+                segs += self.tile_segments_rows(wv, 0, t, True, t + 2 < nt)
+                segs += self.tile_segments_rows(wv, 1, t + 1, t + 2 < nt, t + 3 < nt)
+                t += 2
+            if t < nt:
+                segs += self.tile_segments_rows(wv, 0, t, False, False)
+            if wv.wrow == 0:
+                segs.append(lambda: None)
+            return segs
         if self.half_mode and self.epi == 1 and self.n0 + BN >= self.I:      # half tile: the gate half of this tile is beyond N
             def prologue_half():
                 self.stage_w(wv, 0, 0, 0)
@@ -535,8 +574,8 @@ class Block:
         for wv in self.waves:
             lane = LANES
             ncol = self.n0 + 32 * wv.wcol + 8 * (lane >> 4)
-            for mb in range(8):
-                m = self.m0 + 128 * wv.wrow + 16 * mb + (lane & 15)
+            for mb in range(4 if self.rows_mode else 8):
+                m = self.m0 + (64 if self.rows_mode else 128) * wv.wrow + 16 * mb + (lane & 15)
                 for l in range(64):
                     if m[l] >= self.M:
                         continue
@@ -617,7 +656,7 @@ def gelu_as(x):
     return x - h if x > 0 else h
 
 
-def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False, sched=None, half=False):
+def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None, addends=False, sched=None, half=False, rows=False):
     """epi 0: GEGLU (W [2 I, K]); epi 1: plain projection, I = output columns (W [I, K]); conv = (B, H, W): 3x3 convolution of an
     NHWC image with Cin = K / 9 as an implicit GEMM (M = B H W)."""
     rng = np.random.default_rng(seed)
@@ -631,7 +670,8 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
     row_bias = rng.integers(-8, 9, size=(M // rps, wrows)).astype(np.float64) / 4 if addends else None
     residual = rng.integers(-8, 9, size=(M, wrows)).astype(np.float64) / 4 if addends else None
     nbn = I // BN if epi == 0 else -(-I // (2 * BN))
-    nb = -(-M // BM) * nbn
+    TBM = BM // 2 if rows else BM
+    nb = -(-M // TBM) * nbn
     seen = set()
     for bid in range(nb):
         q, r, xcd = nb >> 3, nb & 7, bid & 7
@@ -643,8 +683,8 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
         rb, cb = first + (tid % per_group) % rows_here, (tid % per_group) // rows_here
         assert 0 <= rb < nbm and 0 <= cb < nbn
         seen.add((rb, cb))
-        blk = Block(x, w, bias, M, K, I, rb * BM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi, conv[1:] if conv else None,
-                    row_bias, residual, rps)
+        blk = Block(x, w, bias, M, K, I, rb * TBM, cb * (BN if epi == 0 else 2 * BN), mode, breakage, epi, conv[1:] if conv else None,
+                    row_bias, residual, rps, rows_mode=rows)
         blk.flip = flip
         blk.sched = sched
         blk.half_mode = half
@@ -674,14 +714,40 @@ def run_case(M, K, I, mode, flip=False, breakage=None, seed=0, epi=0, conv=None,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early", "pf", "half_raw"], default=None)
+    ap.add_argument("--break", dest="breakage", choices=["war", "raw", "lgkm", "early", "pf", "half_raw", "rows_raw"], default=None)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--persist", action="store_true", help="replay the persistent experiment (tools/gemm_persist) instead")
     ap.add_argument("--sched-in-persist", action="store_true", help="with --persist: the 4-interval K loop inside the persistent loop")
     ap.add_argument("--persist2", action="store_true", help="... its v2: the next tile's K tile 0 staged during the last K tile")
     ap.add_argument("--sched", default=None, help="replay a schedule descriptor of tools/gemm_sched (name, or 'all')")
     ap.add_argument("--half", action="store_true", help="replay the half-tile mode of tools/gemm_sched (value half only where the gate half is beyond N)")
+    ap.add_argument("--rows", action="store_true", help="replay the 128-row tile mode (round 6: tile_phases_rows)")
     a = ap.parse_args()
+    if a.breakage == "rows_raw":
+        caught = 0
+        for mode in ("dma_early_read_late", "dma_late_read_early"):
+            try:
+                ok, _ = run_case(256, 448, 256, mode, breakage="rows_raw", epi=1, rows=True)
+            except AssertionError:
+                ok = False
+            caught += not ok
+        print("replay", "caught the deliberately broken schedule" if caught else "DID NOT catch the broken schedule")
+        sys.exit(0 if caught else 1)
+    if a.rows:
+        bad = 0
+        for (M, K, N) in [(300, 256, 104), (128, 192, 320), (200, 448, 384), (128, 64, 640), (260, 128, 200), (128, 512, 256)][:None if not a.quick else 3]:
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                for flip in ((False, True) if mode == "dma_late_read_early" else (False,)):
+                    ok, _ = run_case(M, K, N, mode, flip, epi=1, rows=True)
+                    print(f"128-row tiles M={M} K={K} ({K // BK} K tiles) N={N} {mode:>20s}{' flipped' if flip else ''}: {'exact' if ok else 'WRONG'}")
+                    bad += not ok
+        for (Bn, H, Wd, Cin, N) in [(2, 12, 12, 64, 320), (1, 9, 20, 128, 104)]:
+            for mode in ("dma_early_read_late", "dma_late_read_early"):
+                ok, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd), rows=True)
+                ok2, _ = run_case(Bn * H * Wd, 9 * Cin, N, mode, epi=1, conv=(Bn, H, Wd), addends=True, seed=1, rows=True)
+                print(f"128-row tiles conv3x3 B={Bn} {H}x{Wd} Cin={Cin} N={N} {mode:>20s}: {'exact' if ok else 'WRONG'}; with addends: {'exact' if ok2 else 'WRONG'}")
+                bad += (not ok) + (not ok2)
+        sys.exit(1 if bad else 0)
     if a.breakage == "half_raw":
         caught = 0
         for mode in ("dma_early_read_late", "dma_late_read_early"):
