@@ -382,7 +382,7 @@ __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Fra
 
 // ROWS (round 6): a 128-row tile -- each wave row runs its m-half 0 only (64 rows), both column halves -- for grids that leave the chip
 // under-filled with 256-row tiles: the batch-6 forward's 32 x 32 convolutions are 120 tiles on 256 CUs (240 half-height ones fill 94 % of one
-// round at ~0.55 of a tile's time), a 3-row per-rank forward of the multi-GPU layout 60.  Four barrier intervals per K tile, the structure of
+// round at 0.72 of a tile's time: 1.35-1.45 x, profiles/r6_s4_gemm_rows_mode.jsonl), a 3-row per-rank forward of the multi-GPU layout 60.  Four barrier intervals per K tile, the structure of
 // tile_phases_half with the roles of "x m-half 1" and "W gate rows" exchanged (so the LDS hazard analysis is that one's; replay:
 // tools/emulate_gemm_kernel.py --rows):
 //   R1  W value rows + x m-half 0 (12 fragment reads); W GATE rows of tile + 1 -> the other buffer (its copy was last read in the previous R2)
@@ -880,7 +880,8 @@ static int gemm_cus() {
   }
   return cus[dev];
 }
-constexpr double ROWS_TILE_COST = 0.56;   // time of a 128-row tile relative to a 256-row one (profiles/r6_s4_gemm_rows_mode.jsonl)
+constexpr double ROWS_TILE_COST = 0.72;   // a round of 128-row tiles relative to a round of 256-row ones, measured: 0.71-0.72
+                                          // (profiles/r6_s4_gemm_rows_mode.jsonl: 120 tiles 201.9 -> 144.8 us; 288 tiles 188.8 (2 rounds) vs 200.6 (3))
 
 // C ABI (include/elastic_hip.h).  Returns 0, a hipError_t, or hipErrorInvalidValue for a shape the kernel does not take.
 template <int EPI, bool CONV, bool OUT32 = false>
@@ -902,7 +903,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   const bool two = CONV && K / BK >= TWO_MIN_TILES;     // the long-K loop: convolutions only (measured negative on the plain projections)
   // 128-row tiles (ROWS) where they finish sooner: one workgroup per CU, so a grid runs in rounds of `cus` tiles; a half-height tile costs
   // ROWS_TILE_COST of a full one (W staged and read for half the rows).  120 full tiles (the batch-6 forward's 32 x 32 convolutions):
-  // 1 round vs 0.56; 400: 2 rounds vs 4 x 0.56 -- stays.  ED_GEMM_ROWS=0 / 1 forces it off / on (measurement only).
+  // 1 round vs 0.72; 288: 2 rounds vs 3 x 0.72 -- stays (measured 0.94 x); 400: 2 vs 4 x 0.72 -- stays.  ED_GEMM_ROWS=0 / 1 forces it off / on (measurement only).
   bool rows = false;
   if (!OUT32 && EPI == 1) {
     const int cus = gemm_cus();

@@ -336,10 +336,25 @@ GEMM_CUS = 256                # one 128-KiB-LDS workgroup per CU: the grid runs 
 GEMM_MIN_ROUND_FILL = 0.7     # a multi-round grid whose rounds are on average emptier than this loses to the library's stream-K
 
 
-def _gemm_grid_ok(blocks):
+GEMM_ROWS_TILE_COST = 0.72    # csrc/gemm_kernels.hip ROWS_TILE_COST: a round of 128-row tiles relative to a round of 256-row ones
+GEMM_ROWS_MIN_BLOCKS = 80      # 128-row tiles below which even the half-height grid leaves the chip mostly idle (SD 1.5's 8 x 8 level: 50)
+
+
+def gemm_rows_mode(M, n_col_blocks):
+    """Does the launcher run this grid as 128-row tiles (csrc/gemm_kernels.hip, launch(): fewer effective rounds)?  The mirror of its rule."""
+    b256, b128 = -(-M // GEMM_BM) * n_col_blocks, -(-M // (GEMM_BM // 2)) * n_col_blocks
+    return -(-b128 // GEMM_CUS) * GEMM_ROWS_TILE_COST < -(-b256 // GEMM_CUS) - 1e-9
+
+
+def _gemm_grid_ok(blocks, M=None, n_col_blocks=None):
     """Is a grid of ``blocks`` 256 x 256 tiles worth launching?  Measured (profiles/r4_s2_probe_gemm_*.jsonl): 25 tiles lose
     2.4 x, 100-120 tiles win 1.06-1.18 x (the library under-fills the chip as well), 288 tiles = 2 rounds, the second 12 %
-    full, lose 0.83-0.90 x; 400 tiles (78 %) and everything fuller win."""
+    full, lose 0.83-0.90 x; 400 tiles (78 %) and everything fuller win.  Round 6: an under-filled grid runs as 128-row tiles when that
+    takes fewer effective rounds (``gemm_rows_mode``; profiles/r6_s4_gemm_rows_mode.jsonl: 120 tiles 1.35-1.45 x faster than as 256-row
+    tiles -- 1.95 x MIOpen on the batch-6 32 x 32 convolutions -- and 20-60 tiles, the 1- / 3-row per-rank forwards of the multi-GPU layout,
+    1.24-1.93 x the library call), so such a grid is taken from GEMM_ROWS_MIN_BLOCKS half-height tiles on."""
+    if M is not None and n_col_blocks is not None and gemm_rows_mode(M, n_col_blocks):
+        return -(-M // (GEMM_BM // 2)) * n_col_blocks >= (GEMM_ROWS_MIN_BLOCKS if GEMM_MIN_BLOCKS > 1 else 1)
     if blocks < GEMM_MIN_BLOCKS:
         return False
     rounds = -(-blocks // GEMM_CUS)
@@ -390,8 +405,15 @@ def linear_wins(M, K, N):
     and 6) and SD1.5 (batch 20) forwards (profiles/r4_s2_probe_gemm_*.jsonl): hipBLASLt is weak when K <= 640 or N <= 640
     (388-900 TFLOP/s; this kernel 1.09-1.58 x) and strong on the K >= 1280, N >= 1280 projections (930-1320 TFLOP/s; this
     kernel 0.70-0.95 x there), whenever the grid fills the chip (_gemm_grid_ok)."""
-    return (linear_ok(M, K, N) and (K <= 640 or N <= 640)
-            and _gemm_grid_ok(-(-M // GEMM_BM) * -(-N // (2 * GEMM_BN))))
+    ncb = -(-N // (2 * GEMM_BN))
+    if linear_ok(M, K, N) and K <= 1280 and gemm_rows_mode(M, ncb):
+        # round 6: an under-filled grid as 128-row tiles beats the library up to K = 1280 whatever N (6144 x 1280 -> 1280: 1.06 x,
+        # 3072 x 1280 -> 1280: 1.27 x, 1024 x 1280 -> 1280: 1.24 x); K = 5120 does not (3072 x 5120 -> 1280: 0.74 x -- the library splits K)
+        return _gemm_grid_ok(-(-M // GEMM_BM) * ncb, M, ncb)
+    blocks = -(-M // GEMM_BM) * ncb
+    if K > 1280 and blocks < 200:      # long K on a grid well under one round: the library splits K (12288 x 2560 -> 640, 144 tiles: 0.80 x)
+        return False
+    return linear_ok(M, K, N) and (K <= 640 or N <= 640) and _gemm_grid_ok(blocks)
 
 
 def linear(x, w, bias=None, residual=None):
@@ -419,7 +441,8 @@ def conv3x3_wins(B, H, W, Cin, N):
     """Where ed_conv3x3_nhwc measured faster than MIOpen's CK kernels (fp16, profiles/r4_s2_probe_gemm_*.jsonl): every
     ResnetBlock / upsampler shape whose grid fills the chip -- 1.10-1.59 x at batch 20, 1.06-1.49 x at batch 6 except the
     288-tile 64 x 64 x 640 shapes (0.83-0.90 x: two rounds, the second 12 % full), 0.4 x on SD1.5's 25-tile 8 x 8 level."""
-    return conv3x3_ok(B, H, W, Cin, N) and _gemm_grid_ok(-(-(B * H * W) // GEMM_BM) * -(-N // (2 * GEMM_BN)))
+    ncb = -(-N // (2 * GEMM_BN))
+    return conv3x3_ok(B, H, W, Cin, N) and _gemm_grid_ok(-(-(B * H * W) // GEMM_BM) * ncb, B * H * W, ncb)
 
 
 def conv3x3_nhwc(x, w, bias=None, sample_bias=None, residual=None):
