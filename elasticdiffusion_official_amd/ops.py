@@ -337,6 +337,7 @@ GEMM_MIN_ROUND_FILL = 0.7     # a multi-round grid whose rounds are on average e
 
 
 GEMM_ROWS_TILE_COST = 0.72    # csrc/gemm_kernels.hip ROWS_TILE_COST: a round of 128-row tiles relative to a round of 256-row ones
+GEMM_ROWS_MIN_BLOCKS_LINEAR = 200   # ... for projections (short kernels: the in-situ measurement, linear_wins)
 GEMM_ROWS_MIN_BLOCKS = 80      # 128-row tiles below which even the half-height grid leaves the chip mostly idle (SD 1.5's 8 x 8 level: 50)
 
 
@@ -346,7 +347,7 @@ def gemm_rows_mode(M, n_col_blocks):
     return -(-b128 // GEMM_CUS) * GEMM_ROWS_TILE_COST < -(-b256 // GEMM_CUS) - 1e-9
 
 
-def _gemm_grid_ok(blocks, M=None, n_col_blocks=None):
+def _gemm_grid_ok(blocks, M=None, n_col_blocks=None, min_fill=None):
     """Is a grid of ``blocks`` 256 x 256 tiles worth launching?  Measured (profiles/r4_s2_probe_gemm_*.jsonl): 25 tiles lose
     2.4 x, 100-120 tiles win 1.06-1.18 x (the library under-fills the chip as well), 288 tiles = 2 rounds, the second 12 %
     full, lose 0.83-0.90 x; 400 tiles (78 %) and everything fuller win.  Round 6: an under-filled grid runs as 128-row tiles when that
@@ -358,7 +359,7 @@ def _gemm_grid_ok(blocks, M=None, n_col_blocks=None):
     if blocks < GEMM_MIN_BLOCKS:
         return False
     rounds = -(-blocks // GEMM_CUS)
-    return rounds == 1 or blocks / (rounds * GEMM_CUS) >= GEMM_MIN_ROUND_FILL
+    return rounds == 1 or blocks / (rounds * GEMM_CUS) >= (GEMM_MIN_ROUND_FILL if min_fill is None else min_fill)
 
 
 def _gemm_x(x, name):
@@ -407,9 +408,12 @@ def linear_wins(M, K, N):
     kernel 0.70-0.95 x there), whenever the grid fills the chip (_gemm_grid_ok)."""
     ncb = -(-N // (2 * GEMM_BN))
     if linear_ok(M, K, N) and K <= 1280 and gemm_rows_mode(M, ncb):
-        # round 6: an under-filled grid as 128-row tiles beats the library up to K = 1280 whatever N (6144 x 1280 -> 1280: 1.06 x,
-        # 3072 x 1280 -> 1280: 1.27 x, 1024 x 1280 -> 1280: 1.24 x); K = 5120 does not (3072 x 5120 -> 1280: 0.74 x -- the library splits K)
-        return _gemm_grid_ok(-(-M // GEMM_BM) * ncb, M, ncb)
+        # round 6: an under-filled grid as 128-row tiles beats the library up to K = 1280 whatever N in an isolated loop (6144 x 1280 -> 1280:
+        # 1.06 x, 3072 x 1280 -> 1280: 1.27 x, 4096 x 640 -> 640: 1.40 x; K = 5120 does not -- the library splits K) -- but IN the forward only the
+        # batch-6 shapes keep that (240 half tiles: + 0.35 %); the 40-120-tile grids of the 3- and 1-row forwards measured 1.27-1.40 x alone
+        # cost those forwards 4.0 % and 2.1 % (profiles/r6_s7_policy_split.jsonl: a 128-KiB-LDS workgroup cannot start beside the
+        # previous kernel's tail, the library's small tiles can), so projections are taken from GEMM_ROWS_MIN_BLOCKS_LINEAR half tiles on
+        return -(-M // (GEMM_BM // 2)) * ncb >= GEMM_ROWS_MIN_BLOCKS_LINEAR
     blocks = -(-M // GEMM_BM) * ncb
     if K > 1280 and blocks < 200:      # long K on a grid well under one round: the library splits K (12288 x 2560 -> 640, 144 tiles: 0.80 x)
         return False
@@ -440,9 +444,11 @@ def conv3x3_ok(B, H, W, Cin, N):
 def conv3x3_wins(B, H, W, Cin, N):
     """Where ed_conv3x3_nhwc measured faster than MIOpen's CK kernels (fp16, profiles/r4_s2_probe_gemm_*.jsonl): every
     ResnetBlock / upsampler shape whose grid fills the chip -- 1.10-1.59 x at batch 20, 1.06-1.49 x at batch 6 except the
-    288-tile 64 x 64 x 640 shapes (0.83-0.90 x: two rounds, the second 12 % full), 0.4 x on SD1.5's 25-tile 8 x 8 level."""
+    288-tile 64 x 64 x 640 shapes (0.83-0.90 x in round 4, 1.17 x since round 6), 0.4 x on SD1.5's 25-tile 8 x 8 level."""
     ncb = -(-N // (2 * GEMM_BN))
-    return conv3x3_ok(B, H, W, Cin, N) and _gemm_grid_ok(-(-(B * H * W) // GEMM_BM) * ncb, B * H * W, ncb)
+    # round 6: with the long-K loop, half column tiles and the channel-block-major walk the 288-tile 64 x 64 x 640 shapes of the batch-6
+    # forward now measure 1.17 x MIOpen (profiles/r6_s4_gemm_rows_mode.jsonl; round 4: 0.83-0.90 x): no round-fill condition for convolutions
+    return conv3x3_ok(B, H, W, Cin, N) and _gemm_grid_ok(-(-(B * H * W) // GEMM_BM) * ncb, B * H * W, ncb, min_fill=0.5)
 
 
 def conv3x3_nhwc(x, w, bias=None, sample_bias=None, residual=None):

@@ -92,7 +92,7 @@ def _quiet(stderr):
     return "\n".join(ln for ln in stderr.splitlines() if "MIOpen(HIP): Warning" not in ln)
 
 
-@pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "2", "--in-flight", "2"],
+@pytest.mark.parametrize("flags", [["--gpus", "2"], ["--gpus", "2", "--in-flight", "1"],   # default at N = 2: two images in flight
                                    ["--gpus", "4", "--shard-group", "2", "--in-flight", "2", "--all-layouts"],
                                    ["--gpus", "8"]])   # the driver's largest layout: one 8-way shard group, 4 images in flight
 def test_bench_multi_rank_rehearsal(flags):
@@ -153,7 +153,9 @@ def test_bench_multi_rank_rehearsal(flags):
     comp, tot = d["rows_computed_over_rows_total_rank0"]
     assert 0 < comp <= -(-tot // g) + 2 * 50   # a rank computes ~1/g of the rows, never duplicates of others' rows
     assert d["graphs"]["eager"] == 0
-    if not ("--in-flight" not in flags and g == n):
+    m = int(flags[flags.index("--in-flight") + 1]) if "--in-flight" in flags else max(2, g // 2)
+    assert d["config"]["images_in_flight"] == m
+    if not (g == n and m == 1) and (n == 2 or "--all-layouts" in flags):
         assert "view_parallel_one_image" in d["layouts"]
 
 

@@ -761,9 +761,12 @@ def test_gemm_wrappers_refuse_what_the_kernel_does_not_take():
     assert not ops.linear_wins(20480, 1280, 3840) and ops.linear_wins(81920, 640, 1920) and ops.linear_wins(81920, 2560, 640)
     assert not ops.linear_wins(24576, 640, 640) and ops.linear_wins(24576, 640, 1920)      # 288 tiles: 2 rounds, 56 % full
     assert not ops.conv3x3_ok(20, 128, 128, 4, 320) and ops.conv3x3_wins(20, 32, 32, 1280, 1280) and ops.conv3x3_wins(6, 32, 32, 1280, 1280)
-    assert not ops.conv3x3_wins(6, 64, 64, 640, 640) and not ops.conv3x3_wins(20, 8, 8, 1280, 1280) and ops.conv3x3_ok(20, 8, 8, 1280, 1280)
+    assert ops.conv3x3_wins(6, 64, 64, 640, 640) and not ops.conv3x3_wins(20, 8, 8, 1280, 1280) and ops.conv3x3_ok(20, 8, 8, 1280, 1280)
     # round 6: under-filled grids run as 128-row tiles (profiles/r6_s4_gemm_rows_mode.jsonl) -- the 1- / 3-row per-rank forwards' shapes
     assert ops.gemm_rows_mode(6144, 5) and not ops.gemm_rows_mode(24576, 3) and not ops.gemm_rows_mode(20480, 5)
     assert ops.conv3x3_wins(3, 32, 32, 1280, 1280) and ops.conv3x3_wins(1, 64, 64, 640, 640)
-    assert ops.linear_wins(6144, 1280, 1280) and ops.linear_wins(3072, 1280, 1280) and not ops.linear_wins(3072, 5120, 1280)
+    # projections: only the batch-6 grids (240 half tiles); the 3- / 1-row forwards' 40-120-tile grids won alone and lost in the forward
+    # (profiles/r6_s7_policy_split.jsonl)
+    assert ops.linear_wins(6144, 1280, 1280) and not ops.linear_wins(3072, 1280, 1280) and not ops.linear_wins(3072, 5120, 1280)
+    assert not ops.linear_wins(4096, 640, 640) and not ops.linear_wins(1024, 1280, 1280)
     assert not ops.linear_wins(12288, 2560, 640) and not ops.linear_wins(20480, 1280, 1280)
