@@ -51,6 +51,7 @@ SIGNATURES = {
     "ed_groupnorm_nhwc_s32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_groupnorm_nhwc_workspace": [_i, _i, _i, _i],
+    "ed_groupnorm_nhwc_cat": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "ed_assemble_rows": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                          _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "ed_phase_epilogue": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -63,6 +64,8 @@ SIGNATURES = {
     "ed_geglu_gemm": [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "ed_linear": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp],
     "ed_conv3x3_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_conv3x3_nhwc_up2x": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ed_conv3x3_nhwc_s2": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ed_absmax_f32": [_vp, _i64, _vp, _vp],
     "ed_split_f32_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "ed_groupnorm_nhwc_f32_workspace": [_i, _i, _i, _i],

@@ -162,10 +162,13 @@ struct Ctx {
 // ~64 KB per tile that stays in L2 across the 9 K tiles and is never needed again, where the tap-major walk came back to every pixel's
 // whole Cin vector (328 KB per tile at 128 x 128 x 320, 10 MB for the 32 tiles an XCD runs against 4 MiB of L2) nine times: PMC
 // FETCH_SIZE 6.8 x the algorithmic bytes (profiles/r5_unet_pmc.json).  Same products, another summation order.
+constexpr int CONV_UP2X = 2;   // template value CONV = 2: the 3x3 convolution of the 2x nearest-upsampled input (ed_conv3x3_nhwc_up2x)
+constexpr int CONV_S2 = 3;     // CONV = 3: stride 2, padding 1 (ed_conv3x3_nhwc_s2): output pixel (y, x) at tap (dy, dx) reads input pixel
+                               // (2 y + dy, 2 x + dx) -- the lane's base offset is its input pixel, the tap offsets stay wave-uniform
 struct KPos {
   int tile, tap, ct, w;
 };
-template <bool CONV>
+template <int CONV>
 __device__ __forceinline__ KPos k_next(KPos p, int cpt) {
   ++p.tile;
   if (CONV) {
@@ -183,7 +186,7 @@ __device__ __forceinline__ KPos k_next(KPos p, int cpt) {
 }
 
 // one half tile = 16 subtiles: wave w fills row group `rg` (both k halves) -- 2 LDS-DMAs of 1 KiB
-template <int BUFI, bool CONV>
+template <int BUFI, int CONV>
 __device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, KPos p, int h) {
   const int rg = (c.wave & 3) + 8 * (c.wave >> 2) + 4 * h;   // rows read in phase 1 (h = 0) / phase 3 (h = 1) of either wave row
   uint8_t* dst = lds + BUFI * BUF + x_sub(0, 0) + rg * (2 * SUB);
@@ -191,7 +194,16 @@ __device__ __forceinline__ void stage_x(uint8_t* lds, const Ctx& c, KPos p, int 
   // composable_kernel's ck_tile forces the scalar offset to 0 for these loads on gfx950 -- amd_async_buffer_load)
   if (CONV) {
     const int dy = p.tap / 3 - 1, dx = p.tap - 3 * (p.tap / 3) - 1;              // scalar
-    const int delta = (dy * c.img_w + dx) * c.cin2 + p.ct * (BK * 2);             // scalar, may be negative
+    int delta;
+    if (CONV == CONV_UP2X) {
+      // the A operand is the nearest-neighbour 2x upsampling of x, never written: output pixel (y, x) at tap (dy, dx) reads source pixel
+      // ((y + dy) >> 1, (x + dx) >> 1) = the lane's own source pixel (x_voff) moved by ((y & 1) + dy) >> 1 rows and ((x & 1) + dx) >> 1
+      // pixels of the SOURCE image (c.img_w = its width): per lane, from the two parity bits kept beside the tap mask
+      const int yp = (c.px_mask[h] >> 16) & 1, xp = (c.px_mask[h] >> 17) & 1;
+      delta = (((yp + dy) >> 1) * c.img_w + ((xp + dx) >> 1)) * c.cin2 + p.ct * (BK * 2);
+    } else {
+      delta = (dy * c.img_w + dx) * c.cin2 + p.ct * (BK * 2);                     // scalar, may be negative
+    }
     const int vo = ((c.px_mask[h] >> p.tap) & 1) ? c.x_voff[h] + delta : (int)0x80000000;   // outside the image: out of range = zeros
     __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(c.xr, (lds_ptr_t)(dst + SUB), 16, vo + 64, 0, 0, 0);
@@ -258,7 +270,7 @@ __device__ __forceinline__ void mma16(f32x4 (&acc)[8][4], const Frags<T>& f) {
 // apart, so the barrier that publishes a wave's DMAs to the row that reads first is that row's second barrier of the phase and
 // the other row's first one (16 / 18 DMAs issued by then: 10 outstanding = the first 6 / 8 landed).  Replayed under both
 // adversarial timings in tools/emulate_gemm_kernel.py (`--break early` weakens the count and is caught).
-template <class T, int BUFI, bool CONV, bool FIRST = false>
+template <class T, int BUFI, int CONV, bool FIRST = false>
 __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1,
                                             bool s2, KPos p1, KPos p2) {
   // ---- phase 1: m half 0 x value.  12 fragment reads: the 4 W reads first, so that lgkmcnt(8) retires them before the
@@ -317,7 +329,7 @@ __device__ __forceinline__ void tile_phases(uint8_t* lds, const Ctx& c, Frags<T>
 //   M2  32 MFMAs (m half 1 x gate, value)
 // A wave retires its fragment reads before its barrier.  Replay: tools/emulate_gemm_kernel.py --sched two_read (incl. the convolution).
 constexpr int TWO_MIN_TILES = 20;
-template <class T, int BUFI, bool CONV>
+template <class T, int BUFI, int CONV>
 __device__ __forceinline__ void tile_phases_two(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1, bool s2,
                                                 KPos p1, KPos p2) {
   read_w<T, BUFI, 0>(lds, c, f);
@@ -356,7 +368,7 @@ __device__ __forceinline__ void tile_phases_two(uint8_t* lds, const Ctx& c, Frag
 //   M2  16 MFMAs (m half 1, the W fragments of R1)
 // A wave retires its fragment reads before its barrier (the other wave row is busy with 16 MFMAs meanwhile).  Replayed under both
 // adversarial timings in tools/emulate_gemm_kernel.py --half (--break half_raw weakens the count and is caught).
-template <class T, int BUFI, bool CONV>
+template <class T, int BUFI, int CONV>
 __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], int tile, bool s1, bool s2,
                                                  KPos p1, KPos p2) {
   read_w<T, BUFI, 0>(lds, c, f);
@@ -390,7 +402,7 @@ __device__ __forceinline__ void tile_phases_half(uint8_t* lds, const Ctx& c, Fra
 //   R2  W gate rows (4 reads); W value rows and x m-half 0 of tile + 2 -> this buffer (both last read in R1, by either wave row one interval
 //       ago); vmcnt(4): all of tile + 1 has landed, those two half tiles stay in flight
 //   M2  16 MFMAs (m half 0 x gate)
-template <class T, int BUFI, bool CONV>
+template <class T, int BUFI, int CONV>
 __device__ __forceinline__ void tile_phases_rows(uint8_t* lds, const Ctx& c, Frags<T>& f, f32x4 (&acc)[8][4], bool s1, bool s2, KPos p1,
                                                  KPos p2) {
   read_w<T, BUFI, 0>(lds, c, f);
@@ -430,7 +442,7 @@ __device__ __forceinline__ void tile_phases_rows(uint8_t* lds, const Ctx& c, Fra
 // the fp32 result; out_scale (a power of two) undoes the pre-scaling of the split weights.  row_bias is not used.
 // TWO: the long-K loop (tile_phases_two) instead of the 8-phase one -- a separate instantiation (both loops in one kernel made hipcc spill).
 // ROWS: 128-row tiles (tile_phases_rows) -- a separate instantiation the launcher picks for under-filled grids (launch: rows_mode_pays).
-template <class T, int EPI, bool CONV, bool ADD = true, bool OUT32 = false, bool TWO = false, bool ROWS = false>
+template <class T, int EPI, int CONV, bool ADD = true, bool OUT32 = false, bool TWO = false, bool ROWS = false>
 __global__ void __launch_bounds__(512, 2)
 k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
               const uint16_t* __restrict__ row_bias, const uint16_t* __restrict__ residual, uint16_t* __restrict__ out, int M,
@@ -463,12 +475,13 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   const int ps = swz(16 * lane), srow = ps >> 6, skb = ps & 63;
   const int row_bytes = K * 2;                                   // a W row; for a GEMM also an x row
   const int x_row_bytes = CONV ? row_bytes / 9 : row_bytes;      // CONV: one pixel's Cin values
-  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)M * x_row_bytes), 0x00020000);
+  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)(CONV == CONV_UP2X ? M / 4 : CONV == CONV_S2 ? 4 * (int64_t)M : M) * x_row_bytes),
+                                           0x00020000);
   c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)(EPI == 0 ? 2 : 1) * I * row_bytes), 0x00020000);
   const int xrow0 = m0 + ((c.wave & 3) + (ROWS ? 4 : 8) * (c.wave >> 2)) * 16 + srow;   // the lane's row of m half 0; m half 1 is 64 rows on (ROWS: none)
   c.x_voff[0] = xrow0 * x_row_bytes + skb;
   c.x_voff[1] = c.x_voff[0] + 64 * x_row_bytes;
-  c.img_w = img_w;
+  c.img_w = CONV == CONV_UP2X ? img_w / 2 : CONV == CONV_S2 ? 2 * img_w : img_w;    // width of the SOURCE image (stage_x's tap offsets)
   c.cin2 = x_row_bytes;
   c.cpt = CONV ? K / (9 * BK) : 1;
   c.px_mask[0] = c.px_mask[1] = 0;
@@ -481,10 +494,21 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
         int mask = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-          if (yy >= 0 && yy < img_h && xx >= 0 && xx < img_w) mask |= 1 << t;
+          if (CONV == CONV_S2) {       // input pixel (2 py + dy, 2 px + dx) of the 2 img_h x 2 img_w input: only -1 can fall outside
+            if (2 * py + t / 3 - 1 >= 0 && 2 * px + t % 3 - 1 >= 0) mask |= 1 << t;
+          } else {
+            const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+            if (yy >= 0 && yy < img_h && xx >= 0 && xx < img_w) mask |= 1 << t;
+          }
         }
         c.px_mask[h] = mask;
+        if (CONV == CONV_UP2X) {       // the lane's source pixel and the parities of its output pixel
+          const int hs = img_h / 2, ws = img_w / 2;
+          c.px_mask[h] = mask | ((py & 1) << 16) | ((px & 1) << 17);
+          c.x_voff[h] = ((m / (img_h * img_w)) * (hs * ws) + (py >> 1) * ws + (px >> 1)) * x_row_bytes + skb;
+        }
+        if (CONV == CONV_S2)           // the lane's input pixel (2 py, 2 px)
+          c.x_voff[h] = (((m / (img_h * img_w)) * (2 * img_h) + 2 * py) * (2 * img_w) + 2 * px) * x_row_bytes + skb;
       }
     }
   }
@@ -884,7 +908,7 @@ constexpr double ROWS_TILE_COST = 0.72;   // a round of 128-row tiles relative t
                                           // (profiles/r6_s4_gemm_rows_mode.jsonl: 120 tiles 201.9 -> 144.8 us; 288 tiles 188.8 (2 rounds) vs 200.6 (3))
 
 // C ABI (include/elastic_hip.h).  Returns 0, a hipError_t, or hipErrorInvalidValue for a shape the kernel does not take.
-template <int EPI, bool CONV, bool OUT32 = false>
+template <int EPI, int CONV, bool OUT32 = false>
 static int launch(const void* x, const void* w, const void* bias, const void* row_bias, const void* residual, void* out, int dtype,
                   int64_t M, int K, int I, int img_h, int img_w, int rows_per_sample, void* stream, float out_scale = 1.0f,
                   const float* act_absmax = nullptr) {
@@ -892,6 +916,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   const int bad = (int)hipErrorInvalidValue;
   if (M < 0 || K % BK != 0 || K < BK || I <= 0 || (EPI == 0 ? I % BN != 0 : I % 8 != 0)) return bad;
   if (CONV && (K % (9 * BK) != 0 || img_h <= 0 || img_w <= 0 || M % ((int64_t)img_h * img_w) != 0)) return bad;
+  if (CONV == CONV_UP2X && (img_h % 2 != 0 || img_w % 2 != 0 || row_bias || residual)) return bad;   // (H, W = the OUTPUT size; bias only)
+  if (CONV == CONV_S2 && (row_bias || residual || 4 * M * (int64_t)(K / 9) * 2 >= 0x7ffffff0ll)) return bad;   // (H, W = the OUTPUT size; the input is 2H x 2W)
   if (row_bias && (rows_per_sample <= 0 || M % rows_per_sample != 0)) return bad;
   if (M * (int64_t)(CONV ? K / 9 : K) * 2 >= 0x7ffffff0ll || (int64_t)(EPI == 0 ? 2 : 1) * I * K * 2 >= 0x7ffffff0ll) return bad;   // 32-bit buffer offsets
   if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)row_bias | (uintptr_t)residual) & 15u)) return bad;
@@ -905,7 +931,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   // ROWS_TILE_COST of a full one (W staged and read for half the rows).  120 full tiles (the batch-6 forward's 32 x 32 convolutions):
   // 1 round vs 0.72; 288: 2 rounds vs 3 x 0.72 -- stays (measured 0.94 x); 400: 2 vs 4 x 0.72 -- stays.  ED_GEMM_ROWS=0 / 1 forces it off / on (measurement only).
   bool rows = false;
-  if (!OUT32 && EPI == 1) {
+  if (!OUT32 && EPI == 1 && CONV < CONV_UP2X) {
     const int cus = gemm_cus();
     const double r256 = (double)((nb256 + cus - 1) / cus), r128 = (double)((nb128 + cus - 1) / cus) * ROWS_TILE_COST;
     rows = cus > 0 && r128 < r256 - 1e-9;
@@ -926,8 +952,8 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
       } else {                                                \
         ED_LAUNCH1(TT, ADD_, false, false);                   \
       }                                                       \
-    } else if (rows) {                                        \
-      ED_LAUNCH1(TT, ADD_, false, true);                      \
+    } else if (CONV < CONV_UP2X && rows) {                    \
+      if constexpr (CONV < CONV_UP2X) ED_LAUNCH1(TT, ADD_, false, true);   \
     } else if constexpr (CONV) {                              \
       if (two) ED_LAUNCH1(TT, ADD_, true, false);             \
       else ED_LAUNCH1(TT, ADD_, false, false);                \
@@ -940,7 +966,11 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
     if (add) ED_LAUNCH(HF, true);
     else ED_LAUNCH(HF, false);
   } else {
-    if (dtype == ED_BF16) {
+    if constexpr (CONV >= CONV_UP2X) {   // the up / down-samplers' convolutions: bias only -- no ADD instantiation
+      if (dtype == ED_BF16) ED_LAUNCH(BF, false);
+      else if (dtype == ED_F16) ED_LAUNCH(HF, false);
+      else return bad;
+    } else if (dtype == ED_BF16) {
       if (EPI == 0 || add) ED_LAUNCH(BF, true);
       else ED_LAUNCH(BF, EPI == 0);      // (false for the plain projection / convolution; no second GEGLU instantiation)
     } else if (dtype == ED_F16) {
@@ -982,19 +1012,32 @@ int ed_geglu_gemm(const void* x, const void* w, const void* bias, void* out, int
 
 int ed_linear(const void* x, const void* w, const void* bias, const void* residual, void* out, int dtype, int64_t M, int K, int N,
               void* stream) {
-  return launch<1, false>(x, w, bias, nullptr, residual, out, dtype, M, K, N, 0, 0, 0, stream);
+  return launch<1, 0>(x, w, bias, nullptr, residual, out, dtype, M, K, N, 0, 0, 0, stream);
 }
 
 int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* sample_bias, const void* residual, void* out,
                     int dtype, int B, int H, int W, int Cin, int N, void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
-  return launch<1, true>(x, w, bias, sample_bias, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream);
+  return launch<1, 1>(x, w, bias, sample_bias, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream);
+}
+
+int ed_conv3x3_nhwc_up2x(const void* x, const void* w, const void* bias, void* out, int dtype, int B, int H, int W, int Cin, int N,
+                         void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
+  if ((int64_t)B * (H / 2) * (W / 2) * Cin * 2 >= 0x7ffffff0ll) return (int)hipErrorInvalidValue;
+  return launch<1, CONV_UP2X>(x, w, bias, nullptr, nullptr, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream);
+}
+
+int ed_conv3x3_nhwc_s2(const void* x, const void* w, const void* bias, void* out, int dtype, int B, int H, int W, int Cin, int N,
+                       void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0) return (int)hipErrorInvalidValue;
+  return launch<1, CONV_S2>(x, w, bias, nullptr, nullptr, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream);
 }
 
 int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, const float* residual, float* out, int dtype, int B, int H, int W,
                            int Cin, int N, float out_scale, const float* act_absmax, void* stream) {
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || ((uintptr_t)act_absmax & 3u)) return (int)hipErrorInvalidValue;
-  return launch<1, true, true>(x, w, bias, nullptr, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale,
+  return launch<1, 1, true>(x, w, bias, nullptr, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale,
                                act_absmax);
 }
 

@@ -422,7 +422,7 @@ __device__ __forceinline__ void gn_accumulate8(const Row8<X32>& v, const U16x8& 
 
 template <typename T, bool X32 = false>
 __global__ void __launch_bounds__(GNL_THREADS)
-k_gn_nhwc_partial(const void* __restrict__ x, const uint16_t* __restrict__ conv_bias,
+k_gn_nhwc_partial(const void* __restrict__ x, const void* __restrict__ x2, int C1, const uint16_t* __restrict__ conv_bias,
                   const uint16_t* __restrict__ chan_bias, float* __restrict__ partial, int C, int HW, int G,
                   int rows_per_block) {
   extern __shared__ float sh[];  // [lanes][VC][4]: (sum, sumsq) of the column's first / second group part
@@ -435,7 +435,6 @@ k_gn_nhwc_partial(const void* __restrict__ x, const uint16_t* __restrict__ conv_
   const int my_c = ncol == 1 ? threadIdx.x % VC : threadIdx.x;
   const bool active = ncol == 1 ? (int)threadIdx.x < R * VC : true;
   const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
-  const int64_t base = (int64_t)n * HW * C;                   // element offset of the sample
   const uint16_t* cbn = chan_bias ? chan_bias + (int64_t)n * C : nullptr;
   const bool has_cb = cbn != nullptr, has_kb = conv_bias != nullptr;
   if (active) {
@@ -449,20 +448,25 @@ k_gn_nhwc_partial(const void* __restrict__ x, const uint16_t* __restrict__ conv_
       if (has_kb) kbv = *reinterpret_cast<const U16x8*>(conv_bias + c0);
       if (has_cb) cbv = *reinterpret_cast<const U16x8*>(cbn + c0);
       float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-      const int64_t col = base + c0;
-      const int64_t step = (int64_t)R * C;
+      // two sources (ed_groupnorm_nhwc_cat: the normalised tensor is cat([x, x2], channels), which is never materialised): channels
+      // [0, C1) are columns of x (C1 per pixel), [C1, C) of x2 (C - C1 per pixel); one source: C1 == C
+      const bool second = c0 >= C1;
+      const void* xs = second ? x2 : x;
+      const int cs = second ? C - C1 : C1;
+      const int64_t col = (int64_t)n * HW * cs + (second ? c0 - C1 : c0);
+      const int64_t step = (int64_t)R * cs;
       int row = r0 + my_r;
       for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {  // GNL_UNROLL independent (pairs of) 16-byte loads in flight
-        const int64_t p0 = col + (int64_t)row * C;
+        const int64_t p0 = col + (int64_t)row * cs;
         Row8<X32> v[GNL_UNROLL];
 #pragma unroll
-        for (int u = 0; u < GNL_UNROLL; ++u) v[u].load(x, p0 + u * step);
+        for (int u = 0; u < GNL_UNROLL; ++u) v[u].load(xs, p0 + u * step);
 #pragma unroll
         for (int u = 0; u < GNL_UNROLL; ++u) gn_accumulate8<T, X32>(v[u], kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
       }
       for (; row < r1; row += R) {
         Row8<X32> v;
-        v.load(x, col + (int64_t)row * C);
+        v.load(xs, col + (int64_t)row * cs);
         gn_accumulate8<T, X32>(v, kbv, has_kb, cbv, has_cb, split, s0, q0, s1, q1);
       }
       float* slot = sh + ((int64_t)my_r * VC + vc) * 4;
@@ -537,7 +541,7 @@ k_gn_nhwc_finalize(const float* __restrict__ partial, float* __restrict__ stats_
 // thread's 8 channels are loaded ONCE and it streams rows, GNL_UNROLL at a time.
 template <typename T, bool ACT, bool X32 = false>
 __global__ void __launch_bounds__(GNL_THREADS)
-k_gn_nhwc_apply(const void* __restrict__ x, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+k_gn_nhwc_apply(const void* __restrict__ x, const void* __restrict__ x2, int C1, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
                 const float* __restrict__ stats_all, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block) {
   const int n = blockIdx.y, chunk = blockIdx.x;
@@ -551,7 +555,6 @@ k_gn_nhwc_apply(const void* __restrict__ x, const uint16_t* __restrict__ gamma, 
   if (ncol == 1 && (int)threadIdx.x >= R * VC) return;
   const int r0 = chunk * rows_per_block, r1 = min(HW, r0 + rows_per_block);
   const bool has_cb = chan_bias != nullptr, has_kb = conv_bias != nullptr;
-  const int64_t xb = (int64_t)n * HW * C;                      // element offset of the sample in x
   uint16_t* ob = out + (int64_t)n * HW * C;
 #pragma unroll
   for (int j = 0; j < GNL_MAXCOL; ++j) {
@@ -586,20 +589,24 @@ k_gn_nhwc_apply(const void* __restrict__ x, const uint16_t* __restrict__ gamma, 
       }
       return o;
     };
-    const int64_t step = (int64_t)R * C;
+    const bool second = c0 >= C1;                               // (two sources: see k_gn_nhwc_partial)
+    const void* xs = second ? x2 : x;
+    const int cs = second ? C - C1 : C1;
+    const int64_t xcol = (int64_t)n * HW * cs + (second ? c0 - C1 : c0);
+    const int64_t step = (int64_t)R * C, xstep = (int64_t)R * cs;
     int row = r0 + my_r;
     for (; row + (GNL_UNROLL - 1) * R < r1; row += GNL_UNROLL * R) {
-      const int64_t off = (int64_t)row * C + c0;
+      const int64_t off = (int64_t)row * C + c0, xoff = xcol + (int64_t)row * cs;
       Row8<X32> v[GNL_UNROLL];
 #pragma unroll
-      for (int u = 0; u < GNL_UNROLL; ++u) v[u].load(x, xb + off + u * step);
+      for (int u = 0; u < GNL_UNROLL; ++u) v[u].load(xs, xoff + u * xstep);
 #pragma unroll
       for (int u = 0; u < GNL_UNROLL; ++u) *reinterpret_cast<U16x8*>(ob + off + u * step) = norm(v[u]);
     }
     for (; row < r1; row += R) {
       const int64_t off = (int64_t)row * C + c0;
       Row8<X32> v;
-      v.load(x, xb + off);
+      v.load(xs, xcol + (int64_t)row * cs);
       *reinterpret_cast<U16x8*>(ob + off) = norm(v);
     }
   }
@@ -1121,7 +1128,7 @@ int ed_groupnorm(const void* x, const void* gamma, const void* beta, const void*
   return done();
 }
 
-static int gn_nhwc_launch(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
+static int gn_nhwc_launch(const void* x, const void* x2, int C1, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
                           void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu, bool x32,
                           void* stream) {
   if (N == 0) return 0;
@@ -1129,6 +1136,7 @@ static int gn_nhwc_launch(const void* x, const void* gamma, const void* beta, co
   if (C % G != 0 || C % 8 != 0 || C / G < 8 || G > 256 || C > 8 * GNL_THREADS * GNL_MAXCOL || (x32 && (conv_bias || chan_bias)) ||
       (((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15u))
     return (int)hipErrorInvalidValue;
+  if (x2 ? (C1 <= 0 || C1 >= C || C1 % 8 != 0 || ((uintptr_t)x2 & 15u) || conv_bias || chan_bias) : C1 != C) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const GnPlan pl = gn_plan(N, C, HW);
   float* partial = workspace;                                // [N, nchunks, G, 2]
@@ -1138,16 +1146,16 @@ static int gn_nhwc_launch(const void* x, const void* gamma, const void* beta, co
   size_t lds = sizeof(float) * 4 * (size_t)VC_ * (VC_ <= pl.threads ? pl.threads / VC_ : 1);
   const int rows_per_block = pl.rows_per_block;
 #define GNL_RUN2(T, X32)                                                                                               \
-  k_gn_nhwc_partial<T, X32><<<grid1, pl.threads, lds, s>>>(x, (const uint16_t*)conv_bias,                              \
+  k_gn_nhwc_partial<T, X32><<<grid1, pl.threads, lds, s>>>(x, x2, C1, (const uint16_t*)conv_bias,                              \
                                                            (const uint16_t*)chan_bias, partial, C, HW, G, rows_per_block); \
   k_gn_nhwc_finalize<<<N, GNL_THREADS, 0, s>>>(partial, stats, G, pl.nchunks, (double)HW * (C / G), eps);             \
   if (act_silu)                                                                                                        \
-    k_gn_nhwc_apply<T, true, X32><<<grid1, pl.threads, 0, s>>>(x, (const uint16_t*)gamma,                              \
+    k_gn_nhwc_apply<T, true, X32><<<grid1, pl.threads, 0, s>>>(x, x2, C1, (const uint16_t*)gamma,                              \
                                                          (const uint16_t*)beta, (const uint16_t*)conv_bias,            \
                                                          (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW,     \
                                                          G, rows_per_block);                                           \
   else                                                                                                                 \
-    k_gn_nhwc_apply<T, false, X32><<<grid1, pl.threads, 0, s>>>(x, (const uint16_t*)gamma,                             \
+    k_gn_nhwc_apply<T, false, X32><<<grid1, pl.threads, 0, s>>>(x, x2, C1, (const uint16_t*)gamma,                             \
                                                           (const uint16_t*)beta, (const uint16_t*)conv_bias,           \
                                                           (const uint16_t*)chan_bias, stats, (uint16_t*)out, C, HW,    \
                                                           G, rows_per_block);
@@ -1172,12 +1180,18 @@ static int gn_nhwc_launch(const void* x, const void* gamma, const void* beta, co
 int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const void* conv_bias, const void* chan_bias,
                       void* out, float* workspace, int dtype, int N, int C, int HW, int G, float eps, int act_silu,
                       void* stream) {
-  return gn_nhwc_launch(x, gamma, beta, conv_bias, chan_bias, out, workspace, dtype, N, C, HW, G, eps, act_silu, false, stream);
+  return gn_nhwc_launch(x, nullptr, C, gamma, beta, conv_bias, chan_bias, out, workspace, dtype, N, C, HW, G, eps, act_silu, false, stream);
+}
+
+int ed_groupnorm_nhwc_cat(const void* x1, const void* x2, const void* gamma, const void* beta, void* out, float* workspace, int dtype,
+                          int N, int C1, int C2, int HW, int G, float eps, int act_silu, void* stream) {
+  if (!x1 || !x2 || C1 <= 0 || C2 <= 0) return (int)hipErrorInvalidValue;
+  return gn_nhwc_launch(x1, x2, C1, gamma, beta, nullptr, nullptr, out, workspace, dtype, N, C1 + C2, HW, G, eps, act_silu, false, stream);
 }
 
 int ed_groupnorm_nhwc_s32(const void* x, const void* gamma, const void* beta, void* out, float* workspace, int dtype, int N, int C,
                           int HW, int G, float eps, int act_silu, void* stream) {
-  return gn_nhwc_launch(x, gamma, beta, nullptr, nullptr, out, workspace, dtype, N, C, HW, G, eps, act_silu, true, stream);
+  return gn_nhwc_launch(x, nullptr, C, gamma, beta, nullptr, nullptr, out, workspace, dtype, N, C, HW, G, eps, act_silu, true, stream);
 }
 
 static int layernorm_launch(const void* x, const void* gamma, const void* beta, void* out, int dtype, int64_t M, int D, float eps,

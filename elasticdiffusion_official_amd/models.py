@@ -151,6 +151,10 @@ FLASH_ATTENTION = True      # Attention: ed_flash_attention (head_dim 64, 16-bit
 FUSED_QKV = True            # Attention: one projection GEMM for q,k,v (self) / k,v (cross)
 HIP_GEGLU_GEMM = True       # GEGLU: projection GEMM with the gated product in its epilogue (ed_geglu_gemm) instead of hipBLASLt + ed_geglu
 HIP_LINEAR = True           # the projections where ed_linear measured faster than hipBLASLt (ops.linear_wins)
+FUSED_SKIP_CAT = True        # up blocks: ResnetBlock2D(cat([hidden, skip])) without the concatenated tensor (ed_groupnorm_nhwc_cat + a K-split shortcut)
+FUSED_PROJ_OUT_ADD = True    # Transformer2DModel (channels-last): the closing x + proj_out(h) in ed_linear's residual epilogue
+HIP_DOWNSAMPLE_CONV = True   # Downsample2D (stride 2, padding 1), channels-last: ed_conv3x3_nhwc_s2 instead of MIOpen's CK kernel
+FUSED_UPSAMPLE_CONV = True   # Upsample2D: nearest 2x + conv 3x3 as one ed_conv3x3_nhwc_up2x launch (the A operand is gathered from the source)
 HIP_CONV3X3 = True          # ResnetBlock2D / Upsample2D 3x3 convolutions, channels-last: ed_conv3x3_nhwc (+bias, +temb, +residual) instead of MIOpen
 VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels
 VAE_HIP_ATTENTION = True    # VAE mid-block attention: fp32 GEMM + ed_softmax_rows + fp32 GEMM instead of SDPA (AOTriton)
@@ -412,6 +416,53 @@ class ResnetBlock2D(nn.Module):
         return (x if sc is None else sc(x)) + h
 
 
+def _resnet_forward_cat(self, x, skip, temb=None):
+    """``self(torch.cat([x, skip], 1), temb)`` -- the up blocks' call -- without writing the concatenation (round 6): norm1 reads the two
+    channels-last sources in place (ed_groupnorm_nhwc_cat, bit-identical to the kernel on the materialised cat) and the 1x1 shortcut is
+    split along K, W_sc [x | skip] = W_1 x + W_2 skip: the second product accumulates onto the first (ed_linear's residual epilogue or
+    the library's beta = 1), which rounds the first partial sum to 16 bits once -- the only arithmetic difference from the cat path.
+    Everything else is ``forward``'s channels-last HIP path; any shape / layout it does not take falls back to the concatenation."""
+    sc = self.conv_shortcut
+    if FUSED_SKIP_CAT and FUSED_KERNELS and sc is not None and _fusable_nhwc(x) and _fusable_nhwc(skip) and x.dtype == skip.dtype:
+        from . import ops
+        C1, C = x.shape[1], x.shape[1] + skip.shape[1]
+        cout = self.conv1.out_channels
+        like = x[:, :1]
+        if (ops.groupnorm_nhwc_cat_ok(x, skip, self.norm1.num_groups) and cout % 8 == 0 and cout // self.norm2.num_groups >= 8
+                and self.conv1.weight.shape[1] == C and sc.weight.dtype == x.dtype
+                and _hip_conv3x3(like.expand(-1, C, -1, -1), self.conv1, shape_only=True)
+                and _hip_conv3x3(like.expand(-1, cout, -1, -1), self.conv2, shape_only=True)):
+            tb = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
+            a = ops.groupnorm_nhwc_cat(x, skip, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, silu=True)
+            h = ops.conv3x3_nhwc(a, self.conv1.weight, self.conv1.bias, sample_bias=None if tb is None else tb.contiguous())
+            a = group_norm_act(self.norm2, h, silu=True)
+            w1, w2 = _split_shortcut(sc, C1)
+            xt, st = x.permute(0, 2, 3, 1), skip.permute(0, 2, 3, 1)          # contiguous [N, H, W, C] views of channels-last memory
+            y = linear_(xt, w1, sc.bias)
+            M = st.numel() // st.shape[-1]
+            if HIP_LINEAR and ops.linear_wins(M, st.shape[-1], cout):
+                y = ops.linear(st, w2, None, residual=y)
+            else:
+                y = torch.addmm(y.reshape(M, cout), st.reshape(M, -1), w2.t()).view(y.shape)
+            return ops.conv3x3_nhwc(a, self.conv2.weight, self.conv2.bias, residual=y.permute(0, 3, 1, 2))
+    return self(torch.cat([x, skip], dim=1), temb)
+
+
+def _split_shortcut(sc, C1):
+    """the 1x1 shortcut's weight [cout, C1 + C2, 1, 1] as two contiguous matrices [cout, C1], [cout, C2]; rebuilt when the weight changes"""
+    w = sc.weight
+    key = (id(w), w.data_ptr(), w._version, C1)
+    hit = sc.__dict__.get("_ksplit")
+    if hit is None or hit[0] != key:
+        w2d = w.detach().reshape(w.shape[0], -1)
+        hit = (key, w2d[:, :C1].contiguous(), w2d[:, C1:].contiguous())
+        sc.__dict__["_ksplit"] = hit
+    return hit[1], hit[2]
+
+
+ResnetBlock2D.forward_cat = _resnet_forward_cat
+
+
 def _resnet_forward_split(self, x):
     """The fp32 VAE block with both 3x3 convolutions on the MFMA pipe (VAE_SPLIT_CONV): GroupNorm + SiLU write the split fp16 operand,
     the convolution's fp32 epilogue adds the bias and (conv2) the block's residual.  Batches whose operand would exceed the kernel's
@@ -591,6 +642,14 @@ class Transformer2DModel(nn.Module):
         if s32:
             h = h.to(self.proj_out.weight.dtype)
         if self.linear_proj:
+            if (FUSED_PROJ_OUT_ADD and HIP_LINEAR and FUSED_KERNELS and _fusable_nhwc(x) and _fusable(h) and self.proj_out.weight.dtype == x.dtype == h.dtype
+                    and self.proj_out.weight.is_contiguous()):
+                from . import ops
+                if ops.linear_wins(B * H * W, C, C):
+                    # channels-last: x's memory IS the token layout, so the block's closing `x + proj_out(h)` rides in ed_linear's residual
+                    # epilogue (one rounding of bias + product + residual instead of two) -- no separate add pass
+                    y = ops.linear(h, self.proj_out.weight, self.proj_out.bias, residual=x.permute(0, 2, 3, 1).reshape(B, H * W, C))
+                    return y.view(B, H, W, C).permute(0, 3, 1, 2)
             h = linear_(h, self.proj_out.weight, self.proj_out.bias)
             if (FUSED_TOKENS_ADD and _fusable(x) and _fusable(h) and C % 64 == 0 and (H * W) % 64 == 0):
                 from . import ops
@@ -611,7 +670,14 @@ class Downsample2D(nn.Module):
         if self.padding == 0:  # VAE encoder: asymmetric pad (diffusers Downsample2D)
             x = F.pad(_to_nchw(x), (0, 1, 0, 1))
         if _stream32(x, self.conv.weight.dtype):   # fp32 residual stream: the convolution in the model dtype, its result widened (exact)
-            return self.conv(x.to(self.conv.weight.dtype)).float()
+            return self.forward(x.to(self.conv.weight.dtype)).float()
+        if HIP_DOWNSAMPLE_CONV and HIP_CONV3X3 and self.padding == 1 and _fusable_nhwc(x) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            w = self.conv.weight
+            if w.dtype == x.dtype and w.is_contiguous(memory_format=torch.channels_last):
+                from . import ops
+                B, C, H, W = x.shape
+                if ops.conv3x3_s2_wins(B, H // 2, W // 2, C, w.shape[0]):
+                    return ops.conv3x3_nhwc_s2(x, w, self.conv.bias)       # the stride-2 convolution on the MFMA main loop
         return self.conv(x)
 
 
@@ -650,6 +716,13 @@ class Upsample2D(nn.Module):
                     outs.append(ops.conv3x3_f32out(ops.split_f32(xs, upsample2x=True, absmax=am), w, self.conv.bias, None, sc, act_absmax=am))
                 return outs[0] if len(outs) == 1 else torch.cat(outs).contiguous(memory_format=cl)
             x = _to_nchw(x)  # NCHW for MIOpen's fp32 solvers (the UNet's 16-bit activations stay channels-last)
+        if FUSED_UPSAMPLE_CONV and HIP_CONV3X3 and _fusable_nhwc(x):
+            w = self.conv.weight
+            if w.dtype == x.dtype and w.is_contiguous(memory_format=torch.channels_last):
+                from . import ops
+                B, C, H, W = x.shape
+                if ops.conv3x3_up2x_wins(B, 2 * H, 2 * W, C, w.shape[0]):
+                    return ops.conv3x3_nhwc_up2x(x, w, self.conv.bias)   # the upsampled tensor (4x the source) is never written
         up = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if _hip_conv3x3(up, self.conv):
             from . import ops
@@ -735,7 +808,7 @@ class _UpBlock(nn.Module):
 
     def forward(self, x, skips, temb, ctx, kv=None):
         for i, r in enumerate(self.resnets):
-            x = r(torch.cat([x, skips.pop()], dim=1), temb)
+            x = r.forward_cat(x, skips.pop(), temb)
             if self.attentions is not None:
                 x = self.attentions[i](x, ctx, kv)
         if self.upsamplers is not None:

@@ -475,6 +475,64 @@ def conv3x3_nhwc(x, w, bias=None, sample_bias=None, residual=None):
     return out
 
 
+def conv3x3_up2x_wins(B, H, W, Cin, N):
+    """Where Upsample2D runs as ONE ed_conv3x3_nhwc_up2x launch (H, W = the OUTPUT size): wherever the convolution on the materialised
+    upsampling would run as 256-row tiles of ed_conv3x3_nhwc (the fused kernel has no 128-row instantiation: the upsamplers' grids are
+    80+ tiles per row of the batch) -- the upsampled tensor is then never written or read back (4x the source)."""
+    ncb = -(-N // (2 * GEMM_BN))
+    return (H % 2 == 0 and W % 2 == 0 and conv3x3_wins(B, H, W, Cin, N) and not gemm_rows_mode(B * H * W, ncb)
+            and B * (H // 2) * (W // 2) * Cin * 2 < 2 ** 31 - 16)
+
+
+def conv3x3_nhwc_up2x(x, w, bias=None):
+    """x [B,Cin,H/2,W/2] and w [N,Cin,3,3] channels_last 16-bit -> conv2d(nearest_upsample_2x(x), w, stride 1, padding 1) + bias as
+    channels_last [B,N,H,W]; the upsampled tensor never exists.  See ed_conv3x3_nhwc_up2x."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)):
+        _reject("conv3x3_nhwc_up2x: x must be a 16-bit [B,C,H,W] tensor on the MI355X; no CPU fallback")
+    B, Cin, Hs, Ws = x.shape
+    H, W = 2 * Hs, 2 * Ws
+    N = w.shape[0]
+    cl = torch.channels_last
+    if tuple(w.shape) != (N, Cin, 3, 3) or w.dtype != x.dtype or not conv3x3_ok(B, H, W, Cin, N):
+        _reject(f"conv3x3_nhwc_up2x: unsupported shape x {tuple(x.shape)} w {tuple(w.shape)}")
+    if not x.is_contiguous(memory_format=cl) or not w.is_contiguous(memory_format=cl):
+        _reject("conv3x3_nhwc_up2x: x and w must be channels_last")
+    out = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+    TIMER.note_work("ed_conv3x3_nhwc_up2x", flops=2.0 * B * H * W * 9 * Cin * N, nbytes=2.0 * (B * Hs * Ws * Cin + B * H * W * N + 9 * Cin * N))
+    _call("ed_conv3x3_nhwc_up2x", x.data_ptr(), w.data_ptr(), _opt(bias, x.dtype, "bias"), out.data_ptr(), _code(x, "x"), B, H, W, Cin, N,
+          _stream_of(x))
+    return out
+
+
+def conv3x3_s2_wins(B, H, W, Cin, N):
+    """Where Downsample2D runs as ed_conv3x3_nhwc_s2 (H, W = the OUTPUT size): full grids of 256-row tiles, as for the stride-1 kernel
+    (no 128-row instantiation)."""
+    ncb = -(-N // (2 * GEMM_BN))
+    return (conv3x3_wins(B, H, W, Cin, N) and not gemm_rows_mode(B * H * W, ncb) and 4 * B * H * W * Cin * 2 < 2 ** 31 - 16)
+
+
+def conv3x3_nhwc_s2(x, w, bias=None):
+    """x [B,Cin,2H,2W] and w [N,Cin,3,3] channels_last 16-bit -> conv2d(x, w, stride 2, padding 1) + bias as channels_last [B,N,H,W].
+    See ed_conv3x3_nhwc_s2."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)):
+        _reject("conv3x3_nhwc_s2: x must be a 16-bit [B,C,H,W] tensor on the MI355X; no CPU fallback")
+    B, Cin, Hi, Wi = x.shape
+    if Hi % 2 or Wi % 2:
+        _reject("conv3x3_nhwc_s2: even input height and width")
+    H, W = Hi // 2, Wi // 2
+    N = w.shape[0]
+    cl = torch.channels_last
+    if tuple(w.shape) != (N, Cin, 3, 3) or w.dtype != x.dtype or not conv3x3_ok(B, Hi, Wi, Cin, N):
+        _reject(f"conv3x3_nhwc_s2: unsupported shape x {tuple(x.shape)} w {tuple(w.shape)}")
+    if not x.is_contiguous(memory_format=cl) or not w.is_contiguous(memory_format=cl):
+        _reject("conv3x3_nhwc_s2: x and w must be channels_last")
+    out = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+    TIMER.note_work("ed_conv3x3_nhwc_s2", flops=2.0 * B * H * W * 9 * Cin * N, nbytes=2.0 * (B * Hi * Wi * Cin + B * H * W * N + 9 * Cin * N))
+    _call("ed_conv3x3_nhwc_s2", x.data_ptr(), w.data_ptr(), _opt(bias, x.dtype, "bias"), out.data_ptr(), _code(x, "x"), B, H, W, Cin, N,
+          _stream_of(x))
+    return out
+
+
 GROUPNORM_SPLIT = True  # large groups: statistics + apply as two fully parallel launches (A/B switch)
 
 
@@ -515,6 +573,36 @@ def groupnorm_nhwc(x, gamma, beta, groups, eps, silu=False, chan_bias=None, conv
     _call("ed_groupnorm_nhwc", x.data_ptr(), _dev(gamma, x.dtype, "gamma"), _dev(beta, x.dtype, "beta"),
           _opt(conv_bias, x.dtype, "conv_bias"), _opt(chan_bias, x.dtype, "chan_bias"), out.data_ptr(),
           _dev(ws, torch.float32, "workspace"), _code(x, "x"), N, C, H * W, groups, float(eps), int(silu), _stream())
+    return out
+
+
+def groupnorm_nhwc_cat_ok(x1, x2, groups):
+    """can ed_groupnorm_nhwc_cat normalise cat([x1, x2], 1) of these two tensors in place?"""
+    def cl16(x):
+        return (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)
+                and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last))
+    if not (cl16(x1) and cl16(x2) and x1.dtype == x2.dtype and x1.device == x2.device and x1.shape[0] == x2.shape[0]
+            and x1.shape[2:] == x2.shape[2:]):
+        return False
+    C1, C = x1.shape[1], x1.shape[1] + x2.shape[1]
+    return C1 % 8 == 0 and C % 8 == 0 and C % groups == 0 and C // groups >= 8 and groups <= 256 and C <= 4096
+
+
+def groupnorm_nhwc_cat(x1, x2, gamma, beta, groups, eps, silu=False):
+    """GroupNorm(+SiLU) of torch.cat([x1, x2], dim=1) for two channels_last 16-bit tensors [N,C1,H,W], [N,C2,H,W], read in place
+    (the concatenation is never written) -> channels_last [N, C1 + C2, H, W].  See ed_groupnorm_nhwc_cat."""
+    if not groupnorm_nhwc_cat_ok(x1, x2, groups):
+        _reject("groupnorm_nhwc_cat: two channels_last 16-bit tensors of the same dtype / batch / size on the MI355X, C1 % 8 == 0, "
+                "(C1 + C2) / groups >= 8; no CPU fallback")
+    N, C1, H, W = x1.shape
+    C2 = x2.shape[1]
+    out = torch.empty((N, C1 + C2, H, W), dtype=x1.dtype, device=x1.device, memory_format=torch.channels_last)
+    nbytes = _hip.lib().ed_groupnorm_nhwc_workspace(N, C1 + C2, H * W, groups)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x1.device)
+    TIMER.note_work("ed_groupnorm_nhwc_cat", nbytes=3.0 * out.numel() * out.element_size())
+    _LAUNCH["device"] = x1.device
+    _call("ed_groupnorm_nhwc_cat", x1.data_ptr(), x2.data_ptr(), _dev(gamma, x1.dtype, "gamma"), _dev(beta, x1.dtype, "beta"),
+          out.data_ptr(), ws.data_ptr(), _DTYPE[x1.dtype], N, C1, C2, H * W, groups, float(eps), int(silu), _stream())
     return out
 
 

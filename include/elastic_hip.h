@@ -264,6 +264,17 @@ int ed_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, const 
 int64_t ed_groupnorm_nhwc_workspace(int N, int C, int HW, int G);
 
 /*
+ * ed_groupnorm_nhwc_cat -- ed_groupnorm_nhwc of cat([x1, x2], channel axis) without the concatenated tensor ever existing: the up
+ * blocks' `ResnetBlock2D(torch.cat([hidden, skip], 1))` (diffusers' CrossAttnUpBlock2D / UpBlock2D behind ED:393-432) reads the two
+ * channels-last sources in place.  x1 dtype [N, HW, C1], x2 dtype [N, HW, C2], out dtype [N, HW, C1 + C2]; C1 % 8 == 0 (a 16-byte
+ * vector never straddles the sources; a GROUP may: the statistics are per-column sums).  No folded biases.  Same limits on
+ * C = C1 + C2 and G as ed_groupnorm_nhwc; workspace: ed_groupnorm_nhwc_workspace(N, C1 + C2, HW, G).  Bit-identical to
+ * ed_groupnorm_nhwc on the materialised concatenation.
+ */
+int ed_groupnorm_nhwc_cat(const void* x1, const void* x2, const void* gamma, const void* beta, void* out, float* workspace, int dtype,
+                          int N, int C1, int C2, int HW, int G, float eps, int act_silu, void* stream);
+
+/*
  * ed_assemble_rows -- ed_pick_assemble + ed_gather_views in one launch: all rows of one fused model batch (K CFG pairs
  * of the randomly picked reduced latent + V context crops).  Arguments as in those two entry points ("g" = the global /
  * pick part with its own PH x PW and offsets, "v" = the view part); bit-identical to calling them one after the other.
@@ -375,6 +386,24 @@ int ed_linear(const void* x, const void* w, const void* bias, const void* residu
  */
 int ed_conv3x3_nhwc(const void* x, const void* w, const void* bias, const void* sample_bias, const void* residual, void* out,
                     int dtype, int B, int H, int W, int Cin, int N, void* stream);
+
+/*
+ * ed_conv3x3_nhwc_up2x -- Upsample2D (diffusers: F.interpolate(x, scale_factor = 2, mode = "nearest") + conv 3x3, behind ED:393-432) as ONE
+ * launch: ed_conv3x3_nhwc whose A operand is the 2x nearest-neighbour upsampling of x, never written -- output pixel (y, x) at tap
+ * (dy, dx) reads source pixel ((y + dy) >> 1, (x + dx) >> 1).  x dtype [B, H/2, W/2, Cin] channels-last, H and W = the OUTPUT size (even),
+ * w / bias / out as in ed_conv3x3_nhwc; no sample bias, no residual.  Same products in the same order as ed_conv3x3_nhwc on the
+ * materialised upsampling: bit-identical to it.
+ */
+int ed_conv3x3_nhwc_up2x(const void* x, const void* w, const void* bias, void* out, int dtype, int B, int H, int W, int Cin, int N,
+                         void* stream);
+
+/*
+ * ed_conv3x3_nhwc_s2 -- Downsample2D of the UNet (diffusers: conv 3x3, stride 2, padding 1, behind ED:393-432) on the same main loop: output
+ * pixel (y, x) at tap (dy, dx) reads input pixel (2 y + dy, 2 x + dx), zeros outside.  x dtype [B, 2H, 2W, Cin] channels-last, H and W =
+ * the OUTPUT size, w [N, 3, 3, Cin] / bias [N] / out [B, H, W, N] as in ed_conv3x3_nhwc; no sample bias, no residual.
+ */
+int ed_conv3x3_nhwc_s2(const void* x, const void* w, const void* bias, void* out, int dtype, int B, int H, int W, int Cin, int N,
+                       void* stream);
 
 /*
  * ---- the fp32 VAE's ResnetBlock convolutions on split 16-bit operands (csrc/vae_kernels.hip + the fp32-output epilogue of the

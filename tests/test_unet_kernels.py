@@ -2,6 +2,8 @@
 fp reference = the same op sequence in torch on the same 16-bit tensors; bar: every element within 2 units in the
 last place of the 16-bit type (the kernels round at the same points as torch; the residual is libm / FMA detail),
 and >= 99 % of elements bit-identical."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -142,6 +144,70 @@ def test_groupnorm_channels_last_at_the_unet_shapes_many_chunks(N, C, H, W):
     assert bool((err <= 2.0 * ulp * ref.abs() + 4 * ulp).all()), float(err.max())
     for _ in range(3):
         assert torch.equal(got, ops.groupnorm_nhwc(x, w, b, 32, 1e-5, silu=True))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C1,C2,H,W", [(20, 1280, 1280, 32, 32), (6, 1280, 640, 32, 32), (3, 1280, 640, 64, 64), (2, 640, 320, 64, 64),
+                                         (2, 320, 320, 128, 128), (5, 64, 32, 7, 5), (1, 8, 248, 3, 3)])
+def test_groupnorm_of_a_concatenation_that_is_never_written(dtype, N, C1, C2, H, W):
+    """ed_groupnorm_nhwc_cat (round 6): GroupNorm + SiLU of cat([x1, x2], 1) reading the two channels-last sources in place -- the up
+    blocks' ResnetBlock2D(cat([hidden, skip])).  Groups straddle the seam (C = 1920, 960: 60 / 30 channels per group, seam at 21.33
+    groups).  Bit-identical to ed_groupnorm_nhwc on the materialised concatenation; both activations; wrapper refusals."""
+    from elasticdiffusion_official_amd import ops
+    g = torch.Generator().manual_seed(N * C1 + C2 + H)
+    cl = torch.channels_last
+    x1 = (torch.randn(N, C1, H, W, generator=g) * 1.7 + 0.3).to(DEV, dtype).contiguous(memory_format=cl)
+    x2 = (torch.randn(N, C2, H, W, generator=g) * 0.6 - 1.1).to(DEV, dtype).contiguous(memory_format=cl)
+    C = C1 + C2
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV, dtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV, dtype)
+    G = 32 if C % 32 == 0 and C // 32 >= 8 else 8
+    cat = torch.cat([x1, x2], dim=1).contiguous(memory_format=cl)
+    for silu in (True, False):
+        got = ops.groupnorm_nhwc_cat(x1, x2, w, b, G, 1e-5, silu=silu)
+        assert got.shape == cat.shape and got.is_contiguous(memory_format=cl)
+        assert torch.equal(got, ops.groupnorm_nhwc(cat, w, b, G, 1e-5, silu=silu))
+    ref = F.silu(F.group_norm(cat.float(), G, w.float(), b.float(), 1e-5))
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    err = (ops.groupnorm_nhwc_cat(x1, x2, w, b, G, 1e-5, silu=True).float() - ref).abs()
+    assert bool((err <= 2.0 * ulp * ref.abs() + 4 * ulp).all()), float(err.max())
+    assert not ops.groupnorm_nhwc_cat_ok(x1.contiguous(), x2, G)                       # NCHW memory
+    assert not ops.groupnorm_nhwc_cat_ok(x1, x2.float(), G) and not ops.groupnorm_nhwc_cat_ok(x1, x2[:, :, :-1], G)
+    with pytest.raises(RuntimeError):
+        ops.groupnorm_nhwc_cat(x1, x2.to(torch.float32), w, b, G, 1e-5)
+
+
+@pytest.mark.gpu
+def test_resnet_block_on_a_skip_concatenation_matches_the_cat_path():
+    """ResnetBlock2D.forward_cat (the up blocks' call): norm1 through ed_groupnorm_nhwc_cat, the 1x1 shortcut split along K -- against the same
+    block on torch.cat([x, skip]).  The only arithmetic difference is one 16-bit rounding of the shortcut's first partial sum; the fallback
+    (switch off, fp32 inputs) IS the cat path."""
+    from elasticdiffusion_official_amd import models as M, ops
+    torch.manual_seed(5)
+    cl = torch.channels_last
+    for (B, C1, C2, cout, S) in [(6, 1280, 640, 1280, 32), (2, 640, 320, 640, 64), (1, 320, 320, 320, 128)]:
+        blk = M.ResnetBlock2D(C1 + C2, cout, 1280).to(DEV, torch.float16).eval().requires_grad_(False).to(memory_format=cl)
+        x = torch.randn(B, C1, S, S, device=DEV).half().contiguous(memory_format=cl)
+        skip = (torch.randn(B, C2, S, S, device=DEV) * 0.7).half().contiguous(memory_format=cl)
+        temb = torch.randn(B, 1280, device=DEV).half()
+        ops.TIMER.start()
+        got = blk.forward_cat(x, skip, temb)
+        launched = set(ops.TIMER.stop())
+        assert "ed_groupnorm_nhwc_cat" in launched and "ed_conv3x3_nhwc" in launched, launched
+        want = blk(torch.cat([x, skip], dim=1), temb)
+        ref = blk.float()(torch.cat([x, skip], dim=1).float(), temb.float())
+        blk.half()
+        e_got = float((got.float() - ref).norm() / ref.norm())
+        e_want = float((want.float() - ref).norm() / ref.norm())
+        assert got.shape == want.shape and got.is_contiguous(memory_format=cl)
+        assert e_got < 1.15 * e_want + 2e-5, (e_got, e_want)
+        keep = M.FUSED_SKIP_CAT
+        M.FUSED_SKIP_CAT = False
+        try:
+            assert torch.equal(blk.forward_cat(x, skip, temb), want)
+        finally:
+            M.FUSED_SKIP_CAT = keep
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -720,6 +786,94 @@ def test_conv3x3_nhwc(dtype, B, H, W, Cin, N, any_grid, tile_rows):
         assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all()), float((got.float() - ref).abs().max())
         for _ in range(4):
             assert torch.equal(ops.conv3x3_nhwc(x, w, bias, sbias, res), got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,Hs,Ws,Cin,N", [(2, 6, 10, 64, 200), (3, 8, 8, 128, 320), (1, 16, 16, 320, 320), (2, 4, 4, 1280, 640), (5, 7, 9, 192, 72),
+                                           (2, 32, 32, 1280, 1280), (1, 64, 64, 640, 640)])
+def test_upsampler_convolution_reads_the_source_in_place(dtype, B, Hs, Ws, Cin, N, any_grid):
+    """ed_conv3x3_nhwc_up2x (round 6): Upsample2D = nearest 2x + conv 3x3 as one launch whose A operand is gathered from the low-resolution
+    source (output pixel (y, x), tap (dy, dx) -> source ((y + dy) >> 1, (x + dx) >> 1)): image borders, odd source sizes, batch seams inside a
+    tile, both K loops (Cin = 64 / 128: the 8-phase loop; >= 192: the long-K loop).  Bit-identical to ed_conv3x3_nhwc on the materialised
+    upsampling (same products, same order), within one rounding of fp32 torch, launch-to-launch bit-identical."""
+    from elasticdiffusion_official_amd import ops
+    cl = torch.channels_last
+    g = torch.Generator().manual_seed(B * Hs + Cin)
+    x = _asym((B, Cin, Hs, Ws), g).to(DEV, dtype).contiguous(memory_format=cl)
+    w = _asym((N, Cin, 3, 3), g, (9 * Cin) ** -0.5).to(DEV, dtype).contiguous(memory_format=cl)
+    b = _asym((N,), g).to(DEV, dtype)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    up = F.interpolate(x, scale_factor=2.0, mode="nearest").contiguous(memory_format=cl)
+    for bias in (b, None):
+        got = ops.conv3x3_nhwc_up2x(x, w, bias)
+        assert got.shape == (B, N, 2 * Hs, 2 * Ws) and got.is_contiguous(memory_format=cl)
+        ref = F.conv2d(up.float(), w.float(), None if bias is None else bias.float(), padding=1)
+        assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all()), float((got.float() - ref).abs().max())
+        os.environ["ED_GEMM_ROWS"] = "0"          # (the fused kernel has 256-row tiles only; compare with the same tile height)
+        try:
+            assert torch.equal(got, ops.conv3x3_nhwc(up, w, bias))
+        finally:
+            os.environ.pop("ED_GEMM_ROWS", None)
+        for _ in range(3):
+            assert torch.equal(ops.conv3x3_nhwc_up2x(x, w, bias), got)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_nhwc_up2x(x.contiguous(), w, b)        # NCHW memory
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,N", [(2, 6, 10, 64, 200), (3, 8, 8, 128, 320), (1, 16, 16, 320, 320), (5, 7, 9, 192, 72),
+                                         (2, 64, 64, 320, 320), (3, 32, 32, 640, 640)])
+def test_downsampler_convolution_stride_2(dtype, B, H, W, Cin, N, any_grid, monkeypatch):
+    """ed_conv3x3_nhwc_s2 (round 6): Downsample2D's conv 3x3, stride 2, padding 1 on the MFMA main loop (H, W = the OUTPUT size; output pixel
+    (y, x) at tap (dy, dx) reads input (2 y + dy, 2 x + dx)): top / left padding, odd output sizes, batch seams inside a tile, both K loops.
+    Within one rounding of fp32 torch; launch-to-launch bit-identical; the module takes it on channels-last activations."""
+    from elasticdiffusion_official_amd import models as M, ops
+    cl = torch.channels_last
+    g = torch.Generator().manual_seed(B * H + Cin + 1)
+    x = _asym((B, Cin, 2 * H, 2 * W), g).to(DEV, dtype).contiguous(memory_format=cl)
+    w = _asym((N, Cin, 3, 3), g, (9 * Cin) ** -0.5).to(DEV, dtype).contiguous(memory_format=cl)
+    b = _asym((N,), g).to(DEV, dtype)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for bias in (b, None):
+        got = ops.conv3x3_nhwc_s2(x, w, bias)
+        assert got.shape == (B, N, H, W) and got.is_contiguous(memory_format=cl)
+        ref = F.conv2d(x.float(), w.float(), None if bias is None else bias.float(), stride=2, padding=1)
+        assert bool(((got.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all()), float((got.float() - ref).abs().max())
+        for _ in range(3):
+            assert torch.equal(ops.conv3x3_nhwc_s2(x, w, bias), got)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_nhwc_s2(x[:, :, :-1], w, b)            # odd input height
+    if Cin == N:
+        monkeypatch.setattr(ops, "gemm_rows_mode", lambda *k: False)     # (the policy keeps under-filled grids with the library; the test wants the kernel)
+        down = M.Downsample2D(Cin).to(DEV, dtype).eval().requires_grad_(False).to(memory_format=cl)
+        ops.TIMER.start()
+        y = down(x)
+        assert "ed_conv3x3_nhwc_s2" in set(ops.TIMER.stop())
+        ref = F.conv2d(x.float(), down.conv.weight.float(), down.conv.bias.float(), stride=2, padding=1)
+        assert bool(((y.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all())
+
+
+def test_upsample2d_module_takes_the_fused_kernel():
+    """models.Upsample2D on a channels-last 16-bit activation launches ed_conv3x3_nhwc_up2x (no torch upsample kernel) and equals the
+    unfused path bit for bit; the switch restores the latter."""
+    from elasticdiffusion_official_amd import models as M, ops
+    torch.manual_seed(3)
+    cl = torch.channels_last
+    up = M.Upsample2D(640).to(DEV, torch.float16).eval().requires_grad_(False).to(memory_format=cl)
+    x = torch.randn(6, 640, 32, 32, device=DEV).half().contiguous(memory_format=cl)
+    ops.TIMER.start()
+    got = up(x)
+    launched = set(ops.TIMER.stop())
+    assert "ed_conv3x3_nhwc_up2x" in launched, launched
+    keep = M.FUSED_UPSAMPLE_CONV
+    M.FUSED_UPSAMPLE_CONV = False
+    try:
+        ops.TIMER.start()
+        want = up(x)
+        assert "ed_conv3x3_nhwc_up2x" not in set(ops.TIMER.stop())
+    finally:
+        M.FUSED_UPSAMPLE_CONV = keep
+    assert got.shape == (6, 640, 64, 64) and torch.equal(got, want)
 
 
 def test_gemm_tile_height_is_chosen_by_round_count_and_both_heights_agree(monkeypatch, any_grid):

@@ -1,0 +1,74 @@
+"""Round 6: in-process A/B of model switches on the hipGraph-replayed SDXL forward (one graph per arm, replayed in turn; median).
+Arms: "base" = the named switches OFF, one arm per switch ON alone, "all" = all ON.   python tools/r6_switch_ab.py [--batches 40,12,20,6]"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import elasticdiffusion_official_amd  # noqa: F401
+from elasticdiffusion_official_amd import models as M
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batches", default="40,12,20,6")
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--switches", default="FUSED_SKIP_CAT,FUSED_UPSAMPLE_CONV,FUSED_PROJ_OUT_ADD")
+ap.add_argument("--family", default="sdxl")
+a = ap.parse_args()
+SW = a.switches.split(",")
+cfg = M.UNET_CONFIGS[a.family]
+dt = torch.float16
+torch.manual_seed(0)
+unet = M.UNet2DConditionModel(**cfg).to("cuda", dt).eval().requires_grad_(False).to(memory_format=torch.channels_last)
+S = cfg["sample_size"]
+for batch in [int(v) for v in a.batches.split(",")]:
+    x = torch.randn(batch, 4, S, S, device="cuda", dtype=dt)
+    e = torch.randn(batch, 77, cfg["cross_attention_dim"], device="cuda", dtype=dt)
+    kw = {}
+    if cfg.get("pooled_projection_dim"):
+        kw = {"added_cond_kwargs": {"text_embeds": torch.randn(batch, cfg["pooled_projection_dim"], device="cuda", dtype=dt),
+                                     "time_ids": torch.zeros(batch, 6, device="cuda")}}
+    t = torch.tensor(500, device="cuda")
+    arms = []
+    for name, on in [("base", [])] + [(s, [s]) for s in SW] + [("all", SW)]:
+        for s in SW:
+            setattr(M, s, s in on)
+        with torch.no_grad():
+            kv = unet.cross_attention_kv(e, None)
+            fwd = lambda: unet(x, t, encoder_hidden_states=e, cross_kv=kv, **kw).sample   # noqa: E731
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fwd()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fwd()
+        torch.cuda.synchronize()
+        arms.append({"arm": name, "graph": g, "out": out, "kv": kv, "ms": []})
+    for s in SW:
+        setattr(M, s, True)
+    for arm in arms:
+        arm["graph"].replay()
+    torch.cuda.synchronize()
+    for _ in range(a.reps):
+        for arm in arms:
+            t0 = time.perf_counter()
+            arm["graph"].replay()
+            torch.cuda.synchronize()
+            arm["ms"].append(1e3 * (time.perf_counter() - t0))
+    base = statistics.median(arms[0]["ms"])
+    ref = arms[0]["out"].float()
+    for arm in arms:
+        med = statistics.median(arm["ms"])
+        print(json.dumps({"batch": batch, "arm": arm["arm"], "median_ms": round(med, 3), "min_ms": round(min(arm["ms"]), 3),
+                          "speedup_vs_base": round(base / med, 4),
+                          "rel_l2_vs_base": float(f"{float((arm['out'].float() - ref).norm() / ref.norm()):.3e}")}), flush=True)
+    del arms
+    torch.cuda.empty_cache()
