@@ -153,7 +153,10 @@ HIP_GEGLU_GEMM = True       # GEGLU: projection GEMM with the gated product in i
 HIP_LINEAR = True           # the projections where ed_linear measured faster than hipBLASLt (ops.linear_wins)
 FUSED_SKIP_CAT = True        # up blocks: ResnetBlock2D(cat([hidden, skip])) without the concatenated tensor (ed_groupnorm_nhwc_cat + a K-split shortcut)
 FUSED_PROJ_OUT_ADD = True    # Transformer2DModel (channels-last): the closing x + proj_out(h) in ed_linear's residual epilogue
-HIP_DOWNSAMPLE_CONV = True   # Downsample2D (stride 2, padding 1), channels-last: ed_conv3x3_nhwc_s2 instead of MIOpen's CK kernel
+# Downsample2D (stride 2, padding 1), channels-last, as ed_conv3x3_nhwc_s2 instead of MIOpen's CK kernel: correct (tests) and a TIE in the forward
+# (profiles/r6_s10_switch_ab_downsample.jsonl: +0.3 % at 40 rows, +0.2 % at 12, -0.1 % at 20, -0.2 % at 6 -- N = 320 fills 62 % of its two
+# 256-column tiles), so the library call stays; the entry point and this switch are kept for A/B
+HIP_DOWNSAMPLE_CONV = False
 FUSED_UPSAMPLE_CONV = True   # Upsample2D: nearest 2x + conv 3x3 as one ed_conv3x3_nhwc_up2x launch (the A operand is gathered from the source)
 HIP_CONV3X3 = True          # ResnetBlock2D / Upsample2D 3x3 convolutions, channels-last: ed_conv3x3_nhwc (+bias, +temb, +residual) instead of MIOpen
 VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels

@@ -845,6 +845,7 @@ def test_downsampler_convolution_stride_2(dtype, B, H, W, Cin, N, any_grid, monk
         ops.conv3x3_nhwc_s2(x[:, :, :-1], w, b)            # odd input height
     if Cin == N:
         monkeypatch.setattr(ops, "gemm_rows_mode", lambda *k: False)     # (the policy keeps under-filled grids with the library; the test wants the kernel)
+        monkeypatch.setattr(M, "HIP_DOWNSAMPLE_CONV", True)               # (off by default: a measured tie with the library call)
         down = M.Downsample2D(Cin).to(DEV, dtype).eval().requires_grad_(False).to(memory_format=cl)
         ops.TIMER.start()
         y = down(x)
