@@ -255,7 +255,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="images in flight per shard group (generate_latents_interleaved): their pending model calls are "
                          "fused into one forward.  0 = default: max(2, g // 2) -- two images in flight on one GPU (40- and 12-row "
-                         "forwards instead of 20 and 6: +3.4 ... 4.5 % images/s at twice the latency, measured in rounds 5 and 6; the "
+                         "forwards instead of 20 and 6: +3.4 ... 4.5 %% images/s at twice the latency, measured in rounds 5 and 6; the "
                          "metric is images/sec, and the one-image figure is reported beside it in `extras`); 1 = one image at a time.")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative extra measurements after the timed region")
     ap.add_argument("--all-layouts", action="store_true",

@@ -17,7 +17,7 @@ SOURCES = [os.path.join(PKG_DIR, "csrc", n) for n in ("elastic_kernels.hip", "un
 SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT_DIR, "include")
 SO_PATH = os.path.join(PKG_DIR, "libelastic_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

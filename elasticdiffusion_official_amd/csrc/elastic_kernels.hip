@@ -15,7 +15,7 @@
 
 #include "elastic_hip.h"
 
-#define ED_ABI_VERSION 8
+#define ED_ABI_VERSION 9
 #define ED_BLOCK 256
 
 namespace {

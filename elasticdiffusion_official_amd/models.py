@@ -157,6 +157,12 @@ FUSED_PROJ_OUT_ADD = True    # Transformer2DModel (channels-last): the closing x
 # (profiles/r6_s10_switch_ab_downsample.jsonl: +0.3 % at 40 rows, +0.2 % at 12, -0.1 % at 20, -0.2 % at 6 -- N = 320 fills 62 % of its two
 # 256-column tiles), so the library call stays; the entry point and this switch are kept for A/B
 HIP_DOWNSAMPLE_CONV = False
+# BasicTransformerBlock: x + to_out(...) / x + ff(...) inside ed_linear's epilogue where that kernel runs the projection (the 640-channel level),
+# the following LayerNorm then a plain one.  Measured NO gain in the forward (profiles/r6_s11_switch_ab_residual_linear.jsonl: -0.4 % at 40 rows,
+# -0.3 % at 12, +0.1 % at 20, 0 at 6): the epilogue's residual read costs the projection what ed_add_layernorm -> ed_layernorm saves
+# (profiles/r6_s11_addmm_probe.jsonl: [20480, 1280 -> 1280] projection + add-LayerNorm 94.8 us, own projection with residual + LayerNorm 96.7,
+# library beta = 1 + LayerNorm 103.7).  Off; kept as an A/B switch.
+FUSED_RESIDUAL_LINEAR = False
 FUSED_UPSAMPLE_CONV = True   # Upsample2D: nearest 2x + conv 3x3 as one ed_conv3x3_nhwc_up2x launch (the A operand is gathered from the source)
 HIP_CONV3X3 = True          # ResnetBlock2D / Upsample2D 3x3 convolutions, channels-last: ed_conv3x3_nhwc (+bias, +temb, +residual) instead of MIOpen
 VAE_HIP_GROUPNORM = True    # VAE GroupNorm(+SiLU), fp32 NCHW: ed_groupnorm_f32 instead of torch's moments + affine + SiLU kernels
@@ -204,6 +210,19 @@ def linear_(x, weight, bias=None):
         if ops.linear_wins(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]):
             return ops.linear(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def linear_res_(x, weight, bias, residual):
+    """(F.linear(x, weight, bias) + residual, True) in ONE launch where ed_linear takes the projection (its residual epilogue: bias + product +
+    residual rounded once), else (F.linear(x, weight, bias), False) and the caller adds -- the transformer blocks' `x = x + branch(...)`: with
+    the add inside the projection, the LayerNorm that follows reads and writes 2 units of traffic instead of ed_add_layernorm's 4."""
+    if (FUSED_RESIDUAL_LINEAR and residual is not None and HIP_LINEAR and FUSED_KERNELS and _fusable(x) and _fusable(residual)
+            and weight.dtype == x.dtype == residual.dtype and weight.is_contiguous()
+            and residual.shape == x.shape[:-1] + (weight.shape[0],)):
+        from . import ops
+        if ops.linear_wins(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]):
+            return ops.linear(x, weight, bias, residual=residual), True
+    return linear_(x, weight, bias), False
 
 
 def _hip_conv3x3(x, conv, shape_only=False):
@@ -522,6 +541,16 @@ class Attention(nn.Module):
             cache[slot] = (key, torch.cat(ws, dim=0).contiguous())
         return cache[slot][1]
 
+    def _out_proj(self, o):
+        """to_out[0], with the block's residual in its epilogue when one is pending (forward(residual=...)) and ed_linear runs this shape"""
+        res = self.__dict__.get("_res")
+        if res is not None:
+            y, fused = linear_res_(o, self.to_out[0].weight, self.to_out[0].bias, res)
+            if fused:
+                self.__dict__.pop("_res", None)
+            return y
+        return linear_(o, self.to_out[0].weight, self.to_out[0].bias)
+
     def project_kv(self, context, out=None):
         """k, v of a cross-attention as ONE [B, Nk, 2 inner] tensor (fused weight).  They depend on the text rows only -- not on
         the latent, not on the timestep -- so a caller may compute them once per image and hand them to ``forward`` (``kv``)
@@ -532,7 +561,16 @@ class Attention(nn.Module):
         torch.matmul(context, w.t(), out=out)
         return out
 
-    def forward(self, x, context=None, kv=None):
+    def forward(self, x, context=None, kv=None, residual=None):
+        """``residual`` given: -> (out, fused) -- out = residual + attention(...) when the output projection took the add (fused), else the
+        plain attention output and the caller adds."""
+        if residual is not None:
+            self.__dict__["_res"] = residual
+            try:
+                out = self.forward(x, context, kv)
+            finally:
+                res_state = self.__dict__.pop("_res", None)
+            return out, res_state is None          # _out_proj consumed the residual
         B, N, _ = x.shape
         inner = self.to_q.out_features
         if (FLASH_ATTENTION and _fusable(x) and inner % self.heads == 0 and inner // self.heads in (40, 64, 80, 160)
@@ -549,7 +587,7 @@ class Attention(nn.Module):
                     q = linear_(x, self.to_q.weight if c is None else self._fused_weight(("to_q",), c))
                     k, v = self.to_k(x), self.to_v(x)
                 o = ops.flash_attention(q, k, v, self.heads, prescaled=c is not None)
-                return linear_(o, self.to_out[0].weight, self.to_out[0].bias)
+                return self._out_proj(o)
             else:
                 q = linear_(x, self.to_q.weight)
                 if kv is not None or FUSED_QKV:
@@ -558,7 +596,7 @@ class Attention(nn.Module):
                     k, v = kv[..., :inner], kv[..., inner:]
                 else:
                     k, v = self.to_k(context), self.to_v(context)
-            return linear_(ops.flash_attention(q, k, v, self.heads), self.to_out[0].weight, self.to_out[0].bias)
+            return self._out_proj(ops.flash_attention(q, k, v, self.heads))
         ctx = x if context is None else context
         q = self.to_q(x).view(B, N, self.heads, -1).transpose(1, 2)
         if kv is not None:
@@ -593,7 +631,9 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        if residual is not None:     # -> (out, fused): out = residual + ff(x) when the second projection took the add
+            return linear_res_(self.net[0](x), self.net[2].weight, self.net[2].bias, residual)
         return linear_(self.net[0](x), self.net[2].weight, self.net[2].bias)
 
 
@@ -609,15 +649,20 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, context, pending=None, kv=None):
         """-> (ff_out, x): the block's output is ``ff_out + x``; the caller either hands the pair to the next block
-        (whose norm1 then runs fused with that add) or sums it.  ``pending``: the previous block's ff_out.  ``kv``: dict
+        (whose norm1 then runs fused with that add) or sums it -- or (None, x) when the feed-forward's second projection already
+        added (FUSED_RESIDUAL_LINEAR: wherever ed_linear runs a residual-producing projection the add rides in its epilogue and the
+        next LayerNorm is a plain one).  ``pending``: the previous block's ff_out.  ``kv``: dict
         {id(attention module): precomputed k|v} (UNet.cross_attention_kv) or None."""
         if pending is not None:
             x, h = add_layer_norm(self.norm1, pending, x)                 # x = prev_ff + x ; norm1(x)
         else:
             h = layer_norm(self.norm1, x)
-        x, h = add_layer_norm(self.norm2, self.attn1(h), x)               # x = attn1(norm1(x)) + x ; norm2(x)
-        x, h = add_layer_norm(self.norm3, self.attn2(h, context, None if kv is None else kv.get(id(self.attn2))), x)  # x = attn2(norm2(x)) + x ; norm3(x)
-        return self.ff(h), x
+        a, fused = self.attn1(h, residual=x)                              # x = attn1(norm1(x)) + x ; norm2(x)
+        x, h = (a, layer_norm(self.norm2, a)) if fused else add_layer_norm(self.norm2, a, x)
+        a, fused = self.attn2(h, context, None if kv is None else kv.get(id(self.attn2)), residual=x)   # x = attn2(norm2(x)) + x ; norm3(x)
+        x, h = (a, layer_norm(self.norm3, a)) if fused else add_layer_norm(self.norm3, a, x)
+        a, fused = self.ff(h, residual=x)
+        return (None, a) if fused else (a, x)                              # (None, x): the add already happened in ff's projection
 
 
 class Transformer2DModel(nn.Module):
@@ -641,7 +686,8 @@ class Transformer2DModel(nn.Module):
         pend = None
         for blk in self.transformer_blocks:
             pend, h = blk(h, context, pend, kv)
-        h = pend + h
+        if pend is not None:
+            h = pend + h
         if s32:
             h = h.to(self.proj_out.weight.dtype)
         if self.linear_proj:

@@ -854,6 +854,42 @@ def test_downsampler_convolution_stride_2(dtype, B, H, W, Cin, N, any_grid, monk
         assert bool(((y.float() - ref).abs() <= 1.0 * ulp * ref.abs() + 1e-4).all())
 
 
+def test_transformer_block_residual_adds_inside_the_projections(monkeypatch):
+    """BasicTransformerBlock at the SDXL 640-channel level (where ed_linear runs to_out and the feed-forward's second projection): with
+    FUSED_RESIDUAL_LINEAR the three `x = x + branch` adds ride in the projections' epilogues -- no ed_add_layernorm launch, plain
+    ed_layernorm instead -- and the block's output stays as close to the fp32 block as the unfused path's."""
+    from elasticdiffusion_official_amd import models as M, ops
+    torch.manual_seed(11)
+    blk = M.BasicTransformerBlock(640, 10, 64, 2048).to(DEV, torch.float16).eval().requires_grad_(False)
+    x = torch.randn(20, 4096, 640, device=DEV).half()       # 81920 rows: a grid ed_linear takes (ops.linear_wins)
+    ctx = torch.randn(20, 77, 2048, device=DEV).half()
+    monkeypatch.setattr(M, "FUSED_RESIDUAL_LINEAR", True)   # (off by default: measured no gain in the forward)
+
+    def run():
+        ops.TIMER.start()
+        pend, h = blk(x, ctx)
+        names = set(ops.TIMER.stop())
+        return (h if pend is None else pend + h), names, pend is None
+
+    got, names, summed = run()
+    assert summed and "ed_add_layernorm" not in names and "ed_layernorm" in names and "ed_linear" in names, names
+    monkeypatch.setattr(M, "FUSED_RESIDUAL_LINEAR", False)
+    want, names0, summed0 = run()
+    assert not summed0 and "ed_add_layernorm" in names0
+    keep_all = M.FUSED_KERNELS
+    M.FUSED_KERNELS = False
+    try:
+        blk.float()
+        pend, h = blk(x.float(), ctx.float())
+        ref = pend + h
+    finally:
+        M.FUSED_KERNELS = keep_all
+        blk.half()
+    e_got = float((got.float() - ref).norm() / ref.norm())
+    e_want = float((want.float() - ref).norm() / ref.norm())
+    assert e_got < 1.1 * e_want + 1e-5, (e_got, e_want)
+
+
 def test_upsample2d_module_takes_the_fused_kernel():
     """models.Upsample2D on a channels-last 16-bit activation launches ed_conv3x3_nhwc_up2x (no torch upsample kernel) and equals the
     unfused path bit for bit; the switch restores the latter."""
