@@ -544,7 +544,11 @@ def main():
             for fname in (f"r6_unet_pmc_{args.workload}.json", "r6_unet_pmc.json", f"r5_unet_pmc_{args.workload}.json", "r5_unet_pmc.json", f"r4_unet_pmc_{args.workload}.json", "r4_unet_pmc.json", f"r3_unet_pmc_{args.workload}.json",
                           "r3_unet_pmc.json", "r2_unet_pmc.json"):
                 doc = load_profile_json(fname)
-                if doc and doc.get("workload", "sdxl_1024x2048") == args.workload and dom in doc.get("kernels", {}):
+                # ... and only passes taken at the batch this run's forwards had (rows per forward = 20 / 6 x images in flight / shard ways)
+                want_rows = [-(-(2 * (R + 1) + V) * m // g), -(-(2 + V) * m // g)]
+                if (doc and doc.get("workload", "sdxl_1024x2048") == args.workload and dom in doc.get("kernels", {})
+                        and (doc.get("rows", [20, 6]) == want_rows if args.workload == "sdxl_1024x2048" else (m == 1 and g == 1))):
+                    # (the other workloads' passes, tools/pmc_workload.py, ran one image at a time on one GPU)
                     pmc, pmc_file = doc["kernels"][dom], fname
                     break
             traffic = pmc.get("hbm_bytes_per_launch_mean") if (pmc and T == 50) else None

@@ -71,7 +71,7 @@ def short(name):
         if key in name:
             if key == "k_gemm_8phase":
                 args = [v.strip() for v in name.split("k_gemm_8phase<", 1)[1].split(">", 1)[0].split(",")]   # <T, EPI, CONV, ADD, OUT32, TWO>
-                conv = len(args) > 2 and args[2] == "true"
+                conv = len(args) > 2 and args[2] in ("true", "1", "2", "3")
                 return "k_gemm_8phase" + ("<geglu>" if args[1] == "0" else ("<conv long-K>" if args[-1] == "true" and len(args) > 5 else "<conv>") if conv else "<linear>")
             return key
     return name.split("(")[0][-40:]

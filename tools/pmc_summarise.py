@@ -30,10 +30,14 @@ def entry_of(kernel):
     m = re.search(r"k_gemm_8phase<([^>]*)>", kernel)   # one main loop: <T, EPI, CONV, ADD, OUT32, TWO> (round 5; defaults may be elided)
     if m:
         args = [a.strip() for a in m.group(1).split(",")]
-        epi, conv = args[1], args[2] == "true"
+        epi, conv = args[1], args[2] in ("true", "1", "2", "3")     # CONV: bool until round 5; round 6: 0 GEMM, 1 conv, 2 conv of the 2x upsampling, 3 stride 2
         out32 = len(args) > 4 and args[4] == "true"
         if epi == "0":
             return "ed_geglu_gemm"
+        if args[2] == "2":
+            return "ed_conv3x3_nhwc_up2x"
+        if args[2] == "3":
+            return "ed_conv3x3_nhwc_s2"
         return "ed_conv3x3_nhwc_f32out" if (conv and out32) else ("ed_conv3x3_nhwc" if conv else "ed_linear")
     if "k_geglu_persist" in kernel:
         return "ed_geglu_gemm"
@@ -51,6 +55,11 @@ workload = "sdxl_1024x2048"
 if "--workload" in sys.argv:
     i = sys.argv.index("--workload")
     workload = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+rows = [20, 6]          # rows of the phase-A / phase-B forwards the passes ran (tools/pmc_unet.py ROWS); bench.py matches them with its own
+if "--rows" in sys.argv:
+    i = sys.argv.index("--rows")
+    rows = [int(v) for v in sys.argv[i + 1].split(",")]
     del sys.argv[i:i + 2]
 out_path, dirs = sys.argv[1], sys.argv[2:]
 vals = defaultdict(lambda: defaultdict(list))
@@ -73,7 +82,7 @@ for e, counters in vals.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in r and "SQ_BUSY_CU_CYCLES_mean" in r and r["SQ_BUSY_CU_CYCLES_mean"]:
         r["mfma_busy_over_cu_busy"] = round(r["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / r["SQ_BUSY_CU_CYCLES_mean"], 4)
     res[e] = r
-json.dump({"workload": workload, "note": __doc__.strip().split("usage")[0].strip() + (" Launch mix: one phase-A (20-row) and one phase-B (6-row) "
+json.dump({"workload": workload, "rows": rows, "note": __doc__.strip().split("usage")[0].strip() + (f" Launch mix: one phase-A ({rows[0]}-row) and one phase-B ({rows[1]}-row) "
                    "SDXL forward of the 1024x2048 workload (tools/pmc_unet.py)." if workload == "sdxl_1024x2048" else
                    f" Launch mix: the second of two eager denoising timesteps of bench.py's workload {workload} (tools/pmc_workload.py)."), "kernels": res}, open(out_path, "w"), indent=1)
 print(json.dumps({k: {c: round(v, 1) if isinstance(v, float) else v for c, v in r.items()} for k, r in res.items()}, indent=1))
