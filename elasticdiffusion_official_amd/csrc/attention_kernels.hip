@@ -405,6 +405,38 @@ __device__ __forceinline__ Vec16 buf_load16(BufRsrc rs, uint32_t voff, uint32_t 
   return o;
 }
 
+
+// Output row of one query (head dim 64) from the two lanes that hold it: lane (ln, hi) has dims 32 db + 8 g + 4 hi + e (e < 4) of the row,
+// i.e. 8 bytes of every 16-byte group -- round 5 stored them as 8 `dwordx2` per lane.  The two lanes swap halves (lane ln keeps groups
+// g = 0, 2 whole, lane ln + 32 groups g = 1, 3) and store 4 `dwordx4`: half the store instructions, each a full 16-byte vector
+// (MI355X_MICROARCH.md: the attention store tail is store-ISSUE-bound; dwordx4 halves it).  Same values, same rounding: bit-identical.
+template <typename T>
+__device__ __forceinline__ void store_o_row(uint16_t* orow, const f32x16 (&o)[2], float inv, int hi, bool valid) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    uint32_t part[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x8 tmp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tmp[e] = o[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
+      const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
+      part[g][0] = packed.w[0], part[g][1] = packed.w[1];
+    }
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int ge = 2 * gp, go = 2 * gp + 1;
+      // the partner (lane ^ 32, same query row) needs this lane's half of the group it stores: hi = 0 stores ge, hi = 1 stores go
+      const uint32_t r0 = __shfl_xor(hi ? part[ge][0] : part[go][0], 32, 64);
+      const uint32_t r1 = __shfl_xor(hi ? part[ge][1] : part[go][1], 32, 64);
+      Vec16 out;
+      if (hi) out = Vec16{{r0, r1, part[go][0], part[go][1]}};
+      else out = Vec16{{part[ge][0], part[ge][1], r0, r1}};
+      if (valid) *reinterpret_cast<Vec16*>(orow + 32 * db + 8 * (hi ? go : ge)) = out;
+    }
+  }
+}
+
 struct True { static constexpr bool value = true; };
 struct False { static constexpr bool value = false; };
 
@@ -808,20 +840,7 @@ k_flash_attn_pipe(const Params p) {
 
   const float l_tot = run.l + __shfl_xor(run.l, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (q_row < p.Nq) {
-    uint16_t* orow = og + (int64_t)q_row * p.o_sn;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x8 tmp;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tmp[e] = oacc[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
-        const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
-        Vec8 out8 = {{packed.w[0], packed.w[1]}};
-        *reinterpret_cast<Vec8*>(orow + 32 * db + 8 * g + 4 * hi) = out8;
-      }
-  }
+  store_o_row<T>(og + (int64_t)q_row * p.o_sn, oacc, inv, hi, q_row < p.Nq);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -859,6 +878,8 @@ k_flash_attn_smallkv(const Params p) {
   __syncthreads();
   const float sl = p.scale_log2e;
 
+  // (Round 6: requesting the NEXT query block's rows before the current block's arithmetic -- a register prefetch of 16 VGPRs -- measured
+  // 4-9 % SLOWER, profiles/r6_s14_ops_ab_xattn_prefetch.jsonl: the two workgroups of a CU already overlap each other's loads.)
   for (int qb = 0; qb < SK_QBLOCKS; ++qb) {
     const int q_row = (qgrp * SK_QBLOCKS + qb) * QB + wave * 32 + ln;
     if ((qgrp * SK_QBLOCKS + qb) * QB + wave * 32 >= p.Nq) break;  // wave-uniform: nothing left for this wave
@@ -911,20 +932,7 @@ k_flash_attn_smallkv(const Params p) {
       for (int db = 0; db < 2; ++db)
         o[db] = T::mfma(as_v8<typename T::v8>(v_frag_tr(sm.v, lane, hi, st, db)), pf, o[db]);
     }
-    if (q_row < p.Nq) {
-      uint16_t* orow = og + (int64_t)q_row * p.o_sn;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x8 tmp;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tmp[e] = o[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
-          const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
-          Vec8 out8 = {{packed.w[0], packed.w[1]}};
-          *reinterpret_cast<Vec8*>(orow + 32 * db + 8 * g + 4 * hi) = out8;
-        }
-    }
+    store_o_row<T>(og + (int64_t)q_row * p.o_sn, o, inv, hi, q_row < p.Nq);
   }
 }
 

@@ -77,6 +77,18 @@ def main():
         ref = F.scaled_dot_product_attention(*(t.view(B, N, H, 64).transpose(1, 2).float() for t in (q, k, v))).transpose(1, 2).reshape(B, N, H * 64)
         ab("flash_attention late-maximum rows", libs, lambda: ops.flash_attention(q, k, v, H), 3,
            check=lambda o: {"new_max_abs_err_vs_fp32": float((o["new"].float() - ref).abs().max())})
+    if "xattn" in only:    # the 77-key cross attention (k_flash_attn_smallkv): a streaming kernel -- q read, o written
+        for (B, H, N) in [(40, 10, 4096), (40, 20, 1024), (20, 10, 4096), (20, 20, 1024), (12, 20, 1024), (6, 10, 4096)]:
+            q = torch.randn(B, N, H * 64, generator=g).to(dev, dt)
+            k, v = (torch.randn(B, 77, H * 64, generator=g).to(dev, dt) for _ in range(2))
+            ab(f"flash_attention cross B{B} H{H} N{N} Nk77", libs, lambda: ops.flash_attention(q, k, v, H), a.rounds,
+               extra={"new_gbs": 2.0 * q.numel() * 2 / 1e3})
+    if "attn40" in only:
+        for (B, H, N) in [(40, 10, 4096), (40, 20, 1024), (12, 10, 4096), (12, 20, 1024)]:
+            q, k, v = (torch.randn(B, N, H * 64, generator=g).to(dev, dt) for _ in range(3))
+            flops = 4.0 * B * H * N * N * 64
+            ab(f"flash_attention self B{B} H{H} N{N}", libs, lambda: ops.flash_attention(q, k, v, H), a.rounds,
+               extra={"new_tflops": flops / 1e6})
     if "gn" in only:
         cl = torch.channels_last
         for shape in [(20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1920, 64, 64), (20, 1280, 32, 32), (20, 2560, 32, 32),
