@@ -544,7 +544,9 @@ __global__ void __launch_bounds__(GNL_THREADS)
 k_gn_nhwc_apply(const void* __restrict__ x, const void* __restrict__ x2, int C1, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
                 const uint16_t* __restrict__ conv_bias, const uint16_t* __restrict__ chan_bias,
                 const float* __restrict__ stats_all, uint16_t* __restrict__ out, int C, int HW, int G, int rows_per_block) {
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  // the statistics pass read the tensor front to back; this pass walks it BACK to front (blocks are dispatched in ascending order), so what
+  // it reads first is what the last-level cache saw last -- a tensor larger than the cache is then half served from it instead of not at all
+  const int n = gridDim.y - 1 - blockIdx.y, chunk = gridDim.x - 1 - blockIdx.x;
   const float* stats = stats_all + (int64_t)n * G * 2;
   const int VC = C >> 3, cpg = C / G;
   const int NT = blockDim.x;

@@ -106,7 +106,8 @@ k_gn32_nhwc_apply(const float* __restrict__ x, const float* __restrict__ gamma, 
                   float eps) {
   __shared__ double red[2 * GV_THREADS];
   __shared__ float stats[2 * GV_MAXG];
-  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  // (walked back to front, like the 16-bit kernel's apply pass: what the statistics pass read last is what the last-level cache still holds)
+  const int n = gridDim.y - 1 - blockIdx.y, chunk = gridDim.x - 1 - blockIdx.x, nchunks = gridDim.x;
   {
     const int parts = GV_THREADS / G > 0 ? GV_THREADS / G : 1;
     const int g = threadIdx.x % G, part = threadIdx.x / G;

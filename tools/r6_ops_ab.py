@@ -91,7 +91,7 @@ def main():
                extra={"new_tflops": flops / 1e6})
     if "gn" in only:
         cl = torch.channels_last
-        for shape in [(20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1920, 64, 64), (20, 1280, 32, 32), (20, 2560, 32, 32),
+        for shape in [(40, 320, 128, 128), (40, 640, 64, 64), (40, 1280, 32, 32), (12, 320, 128, 128), (12, 1280, 32, 32), (20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1920, 64, 64), (20, 1280, 32, 32), (20, 2560, 32, 32),
                       (6, 320, 128, 128), (6, 640, 64, 64), (6, 1280, 32, 32)]:
             x = torch.randn(*shape, generator=g).to(dev, dt).contiguous(memory_format=cl)
             C = shape[1]
