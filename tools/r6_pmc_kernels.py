@@ -38,6 +38,22 @@ with torch.no_grad():
         b = (torch.rand(N, device="cuda", generator=g) * 2 - 1).to(dt)
         for _ in range(6):
             ops.conv3x3_nhwc(x, w, b)
+    # round 6: the upsampler convolution that gathers its A operand from the low-resolution source, the 77-key cross attention (output rows as
+    # dwordx4), GroupNorm of a concatenation that is never written
+    x = (torch.rand(20, 1280, 32, 32, device="cuda", generator=g) * 2 - 1).to(dt).contiguous(memory_format=cl)
+    w = ((torch.rand(1280, 1280, 3, 3, device="cuda", generator=g) * 2 - 1) / (9 * 1280) ** 0.5).to(dt).contiguous(memory_format=cl)
+    b = (torch.rand(1280, device="cuda", generator=g) * 2 - 1).to(dt)
+    for _ in range(6):
+        ops.conv3x3_nhwc_up2x(x, w, b)
+    q = torch.randn(20, 4096, 640, device="cuda", generator=g).to(dt)
+    k, v = (torch.randn(20, 77, 640, device="cuda", generator=g).to(dt) for _ in range(2))
+    for _ in range(6):
+        ops.flash_attention(q, k, v, 10)
+    x1 = torch.randn(20, 1280, 32, 32, device="cuda", generator=g).to(dt).contiguous(memory_format=cl)
+    x2 = torch.randn(20, 640, 32, 32, device="cuda", generator=g).to(dt).contiguous(memory_format=cl)
+    gw, gb = torch.ones(1920, device="cuda", dtype=dt), torch.zeros(1920, device="cuda", dtype=dt)
+    for _ in range(6):
+        ops.groupnorm_nhwc_cat(x1, x2, gw, gb, 32, 1e-5, silu=True)
     for shape in ((20, 320, 128, 128), (20, 640, 64, 64), (20, 1280, 32, 32)):
         x = torch.randn(*shape, device="cuda", generator=g).to(dt).contiguous(memory_format=cl)
         gw, gb = torch.ones(shape[1], device="cuda", dtype=dt), torch.zeros(shape[1], device="cuda", dtype=dt)
