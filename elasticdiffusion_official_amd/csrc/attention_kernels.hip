@@ -410,10 +410,10 @@ __device__ __forceinline__ Vec16 buf_load16(BufRsrc rs, uint32_t voff, uint32_t 
 // i.e. 8 bytes of every 16-byte group -- round 5 stored them as 8 `dwordx2` per lane.  The two lanes swap halves (lane ln keeps groups
 // g = 0, 2 whole, lane ln + 32 groups g = 1, 3) and store 4 `dwordx4`: half the store instructions, each a full 16-byte vector
 // (MI355X_MICROARCH.md: the attention store tail is store-ISSUE-bound; dwordx4 halves it).  Same values, same rounding: bit-identical.
-template <typename T>
-__device__ __forceinline__ void store_o_row(uint16_t* orow, const f32x16 (&o)[2], float inv, int hi, bool valid) {
+template <typename T, int NDB = 2>
+__device__ __forceinline__ void store_o_row(uint16_t* orow, const f32x16 (&o)[NDB], float inv, int hi, bool valid, int dh = 64) {
 #pragma unroll
-  for (int db = 0; db < 2; ++db) {
+  for (int db = 0; db < NDB; ++db) {
     uint32_t part[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -432,7 +432,8 @@ __device__ __forceinline__ void store_o_row(uint16_t* orow, const f32x16 (&o)[2]
       Vec16 out;
       if (hi) out = Vec16{{r0, r1, part[go][0], part[go][1]}};
       else out = Vec16{{part[ge][0], part[ge][1], r0, r1}};
-      if (valid) *reinterpret_cast<Vec16*>(orow + 32 * db + 8 * (hi ? go : ge)) = out;
+      const int d0 = 32 * db + 8 * (hi ? go : ge);     // (head dims that are multiples of 8: a group of 8 is inside or outside as a whole)
+      if (valid && d0 < dh) *reinterpret_cast<Vec16*>(orow + d0) = out;
     }
   }
 }
@@ -1109,23 +1110,7 @@ k_flash_attn_gen(const Params p) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (q_row < p.Nq) {
-    uint16_t* orow = og + (int64_t)q_row * p.o_sn;
-#pragma unroll
-    for (int db = 0; db < G::NDB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = 32 * db + 8 * g + 4 * hi;
-        if (d0 < DH) {   // DH % 8 == 0: a group of 4 consecutive d is inside or outside as a whole
-          f32x8 tmp;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tmp[e] = oacc[db][4 * g + e] * inv, tmp[4 + e] = 0.f;
-          const Vec16 packed = __builtin_bit_cast(Vec16, T::pack(tmp));
-          Vec8 out8 = {{packed.w[0], packed.w[1]}};
-          *reinterpret_cast<Vec8*>(orow + d0) = out8;
-        }
-      }
-  }
+  store_o_row<T, G::NDB>(og + (int64_t)q_row * p.o_sn, oacc, inv, hi, q_row < p.Nq, DH);
 }
 
 }  // namespace

@@ -89,6 +89,12 @@ def main():
             flops = 4.0 * B * H * N * N * 64
             ab(f"flash_attention self B{B} H{H} N{N}", libs, lambda: ops.flash_attention(q, k, v, H), a.rounds,
                extra={"new_tflops": flops / 1e6})
+    if "sd1" in only:     # SD 1.x head dims (k_flash_attn_gen): self attention at the 64 x 64 / 32 x 32 / 16 x 16 levels of the 512 x 1024 workload
+        for (B, H, N, hd) in [(20, 8, 4096, 40), (20, 8, 1024, 80), (20, 8, 256, 160), (6, 8, 4096, 40)]:
+            q, k, v = (torch.randn(B, N, H * hd, generator=g).to(dev, dt) for _ in range(3))
+            flops = 4.0 * B * H * N * N * hd
+            ab(f"flash_attention self B{B} H{H} N{N} hd{hd}", libs, lambda: ops.flash_attention(q, k, v, H), a.rounds,
+               extra={"new_tflops": flops / 1e6})
     if "gn" in only:
         cl = torch.channels_last
         for shape in [(40, 320, 128, 128), (40, 640, 64, 64), (40, 1280, 32, 32), (12, 320, 128, 128), (12, 1280, 32, 32), (20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1920, 64, 64), (20, 1280, 32, 32), (20, 2560, 32, 32),
