@@ -71,6 +71,7 @@ SIGNATURES = {
     "ed_groupnorm_nhwc_f32_workspace": [_i, _i, _i, _i],
     "ed_groupnorm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "ed_conv3x3_nhwc_f32out": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
+    "ed_conv3x3_nhwc_f32out_s2": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
 }
 
 _LIB = None

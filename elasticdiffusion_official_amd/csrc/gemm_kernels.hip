@@ -165,6 +165,8 @@ struct Ctx {
 constexpr int CONV_UP2X = 2;   // template value CONV = 2: the 3x3 convolution of the 2x nearest-upsampled input (ed_conv3x3_nhwc_up2x)
 constexpr int CONV_S2 = 3;     // CONV = 3: stride 2, padding 1 (ed_conv3x3_nhwc_s2): output pixel (y, x) at tap (dy, dx) reads input pixel
                                // (2 y + dy, 2 x + dx) -- the lane's base offset is its input pixel, the tap offsets stay wave-uniform
+constexpr int CONV_S2P0 = 4;   // CONV = 4: stride 2 after F.pad(x, (0, 1, 0, 1)) (the VAE encoder's Downsample2D, ed_conv3x3_nhwc_f32out_s2): tap
+                               // (ty, tx) in 0..2 reads input (2 y + ty, 2 x + tx), zeros past the bottom / right edge: the base is pixel (2 y + 1, 2 x + 1)
 struct KPos {
   int tile, tap, ct, w;
 };
@@ -475,13 +477,13 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
   const int ps = swz(16 * lane), srow = ps >> 6, skb = ps & 63;
   const int row_bytes = K * 2;                                   // a W row; for a GEMM also an x row
   const int x_row_bytes = CONV ? row_bytes / 9 : row_bytes;      // CONV: one pixel's Cin values
-  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)(CONV == CONV_UP2X ? M / 4 : CONV == CONV_S2 ? 4 * (int64_t)M : M) * x_row_bytes),
+  c.xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((int64_t)(CONV == CONV_UP2X ? M / 4 : CONV >= CONV_S2 ? 4 * (int64_t)M : M) * x_row_bytes),
                                            0x00020000);
   c.wr_ = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((int64_t)(EPI == 0 ? 2 : 1) * I * row_bytes), 0x00020000);
   const int xrow0 = m0 + ((c.wave & 3) + (ROWS ? 4 : 8) * (c.wave >> 2)) * 16 + srow;   // the lane's row of m half 0; m half 1 is 64 rows on (ROWS: none)
   c.x_voff[0] = xrow0 * x_row_bytes + skb;
   c.x_voff[1] = c.x_voff[0] + 64 * x_row_bytes;
-  c.img_w = CONV == CONV_UP2X ? img_w / 2 : CONV == CONV_S2 ? 2 * img_w : img_w;    // width of the SOURCE image (stage_x's tap offsets)
+  c.img_w = CONV == CONV_UP2X ? img_w / 2 : CONV >= CONV_S2 ? 2 * img_w : img_w;    // width of the SOURCE image (stage_x's tap offsets)
   c.cin2 = x_row_bytes;
   c.cpt = CONV ? K / (9 * BK) : 1;
   c.px_mask[0] = c.px_mask[1] = 0;
@@ -496,6 +498,8 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
         for (int t = 0; t < 9; ++t) {
           if (CONV == CONV_S2) {       // input pixel (2 py + dy, 2 px + dx) of the 2 img_h x 2 img_w input: only -1 can fall outside
             if (2 * py + t / 3 - 1 >= 0 && 2 * px + t % 3 - 1 >= 0) mask |= 1 << t;
+          } else if (CONV == CONV_S2P0) {   // input pixel (2 py + ty, 2 px + tx), ty / tx = 0..2: only the row / column past the edge falls outside
+            if (2 * py + t / 3 < 2 * img_h && 2 * px + t % 3 < 2 * img_w) mask |= 1 << t;
           } else {
             const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
             if (yy >= 0 && yy < img_h && xx >= 0 && xx < img_w) mask |= 1 << t;
@@ -507,8 +511,10 @@ k_gemm_8phase(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, co
           c.px_mask[h] = mask | ((py & 1) << 16) | ((px & 1) << 17);
           c.x_voff[h] = ((m / (img_h * img_w)) * (hs * ws) + (py >> 1) * ws + (px >> 1)) * x_row_bytes + skb;
         }
-        if (CONV == CONV_S2)           // the lane's input pixel (2 py, 2 px)
-          c.x_voff[h] = (((m / (img_h * img_w)) * (2 * img_h) + 2 * py) * (2 * img_w) + 2 * px) * x_row_bytes + skb;
+        if (CONV >= CONV_S2) {         // the lane's base input pixel: (2 py, 2 px), or (2 py + 1, 2 px + 1) for the pad-(0, 1, 0, 1) variant
+          const int o1 = CONV == CONV_S2P0 ? 1 : 0;
+          c.x_voff[h] = (((m / (img_h * img_w)) * (2 * img_h) + 2 * py + o1) * (2 * img_w) + 2 * px + o1) * x_row_bytes + skb;
+        }
       }
     }
   }
@@ -917,7 +923,7 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   if (M < 0 || K % BK != 0 || K < BK || I <= 0 || (EPI == 0 ? I % BN != 0 : I % 8 != 0)) return bad;
   if (CONV && (K % (9 * BK) != 0 || img_h <= 0 || img_w <= 0 || M % ((int64_t)img_h * img_w) != 0)) return bad;
   if (CONV == CONV_UP2X && (img_h % 2 != 0 || img_w % 2 != 0 || row_bias || residual)) return bad;   // (H, W = the OUTPUT size; bias only)
-  if (CONV == CONV_S2 && (row_bias || residual || 4 * M * (int64_t)(K / 9) * 2 >= 0x7ffffff0ll)) return bad;   // (H, W = the OUTPUT size; the input is 2H x 2W)
+  if (CONV >= CONV_S2 && (row_bias || residual || 4 * M * (int64_t)(K / 9) * 2 >= 0x7ffffff0ll)) return bad;   // (H, W = the OUTPUT size; the input is 2H x 2W)
   if (row_bias && (rows_per_sample <= 0 || M % rows_per_sample != 0)) return bad;
   if (M * (int64_t)(CONV ? K / 9 : K) * 2 >= 0x7ffffff0ll || (int64_t)(EPI == 0 ? 2 : 1) * I * K * 2 >= 0x7ffffff0ll) return bad;   // 32-bit buffer offsets
   if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)row_bias | (uintptr_t)residual) & 15u)) return bad;
@@ -963,8 +969,12 @@ static int launch(const void* x, const void* w, const void* bias, const void* ro
   } while (0)
   if constexpr (OUT32) {       // split-fp16 operands only (bf16's 8 significand bits would need three terms per operand)
     if (dtype != ED_F16 || row_bias) return bad;
-    if (add) ED_LAUNCH(HF, true);
-    else ED_LAUNCH(HF, false);
+    if constexpr (CONV >= CONV_UP2X) {
+      ED_LAUNCH(HF, false);      // (bias only: no ADD instantiation)
+    } else {
+      if (add) ED_LAUNCH(HF, true);
+      else ED_LAUNCH(HF, false);
+    }
   } else {
     if constexpr (CONV >= CONV_UP2X) {   // the up / down-samplers' convolutions: bias only -- no ADD instantiation
       if (dtype == ED_BF16) ED_LAUNCH(BF, false);
@@ -1039,6 +1049,13 @@ int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, cons
   if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || ((uintptr_t)act_absmax & 3u)) return (int)hipErrorInvalidValue;
   return launch<1, 1, true>(x, w, bias, nullptr, residual, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale,
                                act_absmax);
+}
+
+int ed_conv3x3_nhwc_f32out_s2(const void* x, const void* w, const float* bias, float* out, int dtype, int B, int H, int W, int Cin, int N,
+                              float out_scale, const float* act_absmax, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || Cin <= 0 || ((uintptr_t)act_absmax & 3u)) return (int)hipErrorInvalidValue;
+  return launch<1, CONV_S2P0, true>(x, w, bias, nullptr, nullptr, out, dtype, (int64_t)B * H * W, 9 * Cin, N, H, W, H * W, stream, out_scale,
+                                    act_absmax);
 }
 
 }  // extern "C"

@@ -180,6 +180,7 @@ VAE_NCHW_RESIDUAL = True
 # convolutions, conv_in / conv_out and the mid-block attention stay with the fp32 libraries in NCHW (_to_nchw: one layout copy per block
 # boundary).  As accurate against fp64 as the library's fp32 convolution (tests/test_vae_split.py).
 VAE_SPLIT_CONV = True
+VAE_SPLIT_DOWNSAMPLE = True   # round 6: the encoder's stride-2 downsamplers on the split-operand path as well (ed_conv3x3_nhwc_f32out_s2)
 # A/B switch from the environment: ED_DISABLE=FLASH_ATTENTION,FUSED_QKV,... turns the named module switches off
 for _name in filter(None, os.environ.get("ED_DISABLE", "").split(",")):
     if _name not in globals() or not isinstance(globals()[_name], bool):
@@ -283,6 +284,8 @@ def prepare_vae_split(vae):
         if isinstance(m, ResnetBlock2D) and m.time_emb_proj is None:
             convs = (m.conv1, m.conv2)
         elif isinstance(m, Upsample2D) and m.vae:
+            convs = (m.conv,)
+        elif isinstance(m, Downsample2D) and m.padding == 0:     # the VAE encoder's downsamplers (VAE_SPLIT_DOWNSAMPLE)
             convs = (m.conv,)
         for c in convs:
             w = c.weight
@@ -716,6 +719,23 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=padding)
 
     def forward(self, x):
+        if self.padding == 0 and VAE_SPLIT_CONV and VAE_SPLIT_DOWNSAMPLE and FUSED_KERNELS and x.is_cuda and x.dtype == torch.float32 \
+                and x.dim() == 4 and self.conv.weight.dtype == torch.float32:
+            # the VAE encoder's downsampler on the MFMA pipe (round 6): the raw stream is split like the decoder's upsampler input (per-tensor
+            # power-of-two scale from its absolute maximum), the pad-(0, 1, 0, 1) stride-2 convolution is template value CONV = 4 of the
+            # split-operand main loop; channels-last in and out -- no NCHW copies around the library call
+            from . import ops
+            B, C, H, W = x.shape
+            if C % 64 == 0 and ops.conv3x3_f32out_s2_ok(1, H, W, 3 * C, self.conv.weight.shape[0]):
+                w, sc = _split_weight(self.conv)
+                x = x.contiguous(memory_format=torch.channels_last)
+                nb = max(1, (2 ** 31 - 16) // (H * W * 3 * C * 2))
+                outs = []
+                for i in range(0, B, nb):
+                    xs = x[i:i + nb]
+                    am = ops.absmax_f32(xs)
+                    outs.append(ops.conv3x3_f32out_s2(ops.split_f32(xs, absmax=am), w, self.conv.bias, sc, act_absmax=am))
+                return outs[0] if len(outs) == 1 else torch.cat(outs).contiguous(memory_format=torch.channels_last)
         if self.padding == 0:  # VAE encoder: asymmetric pad (diffusers Downsample2D)
             x = F.pad(_to_nchw(x), (0, 1, 0, 1))
         if _stream32(x, self.conv.weight.dtype):   # fp32 residual stream: the convolution in the model dtype, its result widened (exact)

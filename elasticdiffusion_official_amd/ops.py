@@ -829,6 +829,33 @@ def conv3x3_f32out(a, w, bias=None, residual=None, out_scale=1.0, act_absmax=Non
     return out
 
 
+def conv3x3_f32out_s2_ok(B, Hi, Wi, Cin3, N):
+    """can ed_conv3x3_nhwc_f32out_s2 take a split operand [B, Cin3, Hi, Wi] (the INPUT size)?"""
+    return (Hi % 2 == 0 and Wi % 2 == 0 and Cin3 % 64 == 0 and N % 8 == 0 and B * Hi * Wi * Cin3 * 2 < 2 ** 31 - 16
+            and N * 9 * Cin3 * 2 < 2 ** 31 - 16)
+
+
+def conv3x3_f32out_s2(a, w, bias=None, out_scale=1.0, act_absmax=None):
+    """a [B,Cin',2H,2W] fp16 split operand (``split_f32`` of the raw fp32 stream) and w [N,Cin',3,3] fp16 (``split_conv_weight``), channels_last ->
+    out_scale * conv2d(F.pad(a, (0, 1, 0, 1)), w, stride 2) + bias as fp32 channels_last [B,N,H,W]: the VAE encoder's Downsample2D at fp32
+    accuracy on the MFMA pipe.  See ed_conv3x3_nhwc_f32out_s2."""
+    if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dim() == 4 and a.dtype == torch.float16):
+        _reject("conv3x3_f32out_s2: a must be an fp16 [B,C,H,W] tensor on the MI355X; no CPU fallback")
+    B, C3, Hi, Wi = a.shape
+    N = w.shape[0]
+    cl = torch.channels_last
+    if tuple(w.shape) != (N, C3, 3, 3) or w.dtype != torch.float16 or not conv3x3_f32out_s2_ok(B, Hi, Wi, C3, N):
+        _reject(f"conv3x3_f32out_s2: unsupported shape a {tuple(a.shape)} w {tuple(w.shape)}")
+    if not a.is_contiguous(memory_format=cl) or not w.is_contiguous(memory_format=cl):
+        _reject("conv3x3_f32out_s2: a and w must be channels_last")
+    H, W = Hi // 2, Wi // 2
+    out = torch.empty((B, N, H, W), dtype=torch.float32, device=a.device, memory_format=cl)
+    TIMER.note_work("ed_conv3x3_nhwc_f32out_s2", flops=2.0 * B * H * W * 9 * C3 * N, nbytes=2.0 * (B * Hi * Wi * C3 + 9 * C3 * N) + 4.0 * B * H * W * N)
+    _call("ed_conv3x3_nhwc_f32out_s2", a.data_ptr(), w.data_ptr(), _opt(bias, torch.float32, "bias"), out.data_ptr(), _DTYPE[torch.float16],
+          B, H, W, C3, N, float(out_scale), None if act_absmax is None else act_absmax.data_ptr(), _stream_of(a))
+    return out
+
+
 def softmax_rows_(x, scale=1.0):
     """x fp32 [..., cols] contiguous -> softmax(scale * x) over the last dim, IN PLACE (ed_softmax_rows)."""
     cols = x.shape[-1]

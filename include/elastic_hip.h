@@ -442,6 +442,15 @@ int ed_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, vo
 int ed_conv3x3_nhwc_f32out(const void* x, const void* w, const float* bias, const float* residual, float* out, int dtype, int B, int H, int W,
                            int Cin, int N, float out_scale, const float* act_absmax, void* stream);
 
+/*
+ * ed_conv3x3_nhwc_f32out_s2 -- the VAE encoder's Downsample2D (diffusers: F.pad(x, (0, 1, 0, 1)) + conv 3x3, stride 2, padding 0; AutoencoderKL
+ * behind ED:327-364) on the split-operand main loop at fp32 accuracy: output pixel (y, x) at tap (ty, tx) in 0..2 reads input pixel
+ * (2 y + ty, 2 x + tx), zeros past the bottom / right edge.  x fp16 [B, 2H, 2W, Cin'] = the split operand of the raw fp32 stream
+ * (ed_split_f32_nhwc; Cin' = 3 Cin), H and W = the OUTPUT size, w / bias / out / out_scale / act_absmax as in ed_conv3x3_nhwc_f32out; no residual.
+ */
+int ed_conv3x3_nhwc_f32out_s2(const void* x, const void* w, const float* bias, float* out, int dtype, int B, int H, int W, int Cin, int N,
+                              float out_scale, const float* act_absmax, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,36 @@ def test_vae_upsampler_split_vs_library():
     assert e <= max(2.0 * elib, 6e-7), (e, elib)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,cout,H,W", [(3, 128, 128, 20, 28), (1, 256, 256, 18, 6), (2, 512, 512, 8, 8), (5, 128, 128, 64, 256)])
+def test_vae_downsampler_split_vs_library(B, C, cout, H, W):
+    """The VAE encoder's Downsample2D -- F.pad(x, (0, 1, 0, 1)) + conv 3x3, stride 2 -- on the split-operand main loop (round 6,
+    ed_conv3x3_nhwc_f32out_s2: template value CONV = 4; bottom / right taps past the edge read zeros): as accurate against fp64 as the
+    library's fp32 convolution, channels-last out, launch-to-launch bit-identical; values beyond fp16's range go through the absmax scale."""
+    from elasticdiffusion_official_amd import models as M, ops
+    dev = "cuda:0"
+    torch.manual_seed(B + C)
+    down = M.Downsample2D(C, padding=0).to(dev).eval().requires_grad_(False)
+    x = torch.randn(B, C, H, W, device=dev) * 4
+    x[0, :, H // 2, W // 2] *= 3.0e4          # a stream that leaves fp16's range (the real VAE's does)
+    want = F.conv2d(F.pad(x.double(), (0, 1, 0, 1)), down.conv.weight.double(), down.conv.bias.double(), stride=2)
+    saved = M.VAE_SPLIT_DOWNSAMPLE
+    try:
+        M.VAE_SPLIT_DOWNSAMPLE = False
+        lib = down(x)
+        M.VAE_SPLIT_DOWNSAMPLE = True
+        ops.TIMER.start()
+        got = down(x)
+        assert "ed_conv3x3_nhwc_f32out_s2" in ops.TIMER.stop()
+        again = down(x)
+    finally:
+        M.VAE_SPLIT_DOWNSAMPLE = saved
+    assert got.shape == lib.shape == (B, cout, H // 2, W // 2) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, again)
+    e, elib = _rel(got, want), _rel(lib, want)
+    assert e <= max(2.0 * elib, 6e-7), (e, elib)
+
+
 # ---- round 6 (ADVICE r5): the raw-stream split is exact over the WHOLE fp32 range ----------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("peak", [3.0e4, 7.0e4, 1.4e5, 2.5e6, 3.0e9, 1.0e30])

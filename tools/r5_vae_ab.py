@@ -40,6 +40,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="encode,decode,tiles")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--switch", default="VAE_SPLIT_CONV", help="the models switch the two arms differ in (round 6: VAE_SPLIT_DOWNSAMPLE -- the encoder's "
+                                                              "stride-2 downsamplers on the split path, with VAE_SPLIT_CONV on in both arms)")
     a = ap.parse_args()
     dev = "cuda:0"
     with torch.device("meta"):
@@ -60,7 +62,7 @@ def main():
         outs = {}
         with torch.no_grad():
             for flag in (False, True):
-                M.VAE_SPLIT_CONV = flag
+                setattr(M, a.switch, flag)
                 ms, out = timed(lambda: fn(inp), a.reps)
                 res["split_ms" if flag else "library_ms"] = round(ms, 2)
                 outs[flag] = out
