@@ -4,14 +4,14 @@
 #   4 rocprofv3 --kernel-trace --stats of a bench run (+ trace summary)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r6final; mkdir -p $O
+O=gpurun_out/r6final2; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu_full.log 2>&1; tail -5 $O/pytest_gpu_full.log
 ( time timeout 600 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; tail -4 $O/smoke.log
 ( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_final.json 2> $O/bench_final.err
 python - <<'PY'
 import json
 try:
-    d = json.loads([l for l in open("gpurun_out/r6final/bench_final.json") if l.startswith("{")][-1])
+    d = json.loads([l for l in open("gpurun_out/r6final2/bench_final.json") if l.startswith("{")][-1])
     r = d.get("roofline") or {}
     print("final", d["value"], d["ms_per_step"], d["config"]["images_in_flight"], d.get("latency_s_per_image"), d["roofline_e2e"]["frac"], r.get("kernel"), r.get("frac"), r.get("us_per_launch"), r.get("traffic"))
     print(json.dumps(d["tolerance"].get("fp32_unet_same_workload"))[:500], d["tolerance"].get("meets_1e-3"))
