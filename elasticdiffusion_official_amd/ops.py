@@ -470,9 +470,44 @@ def conv3x3_nhwc(x, w, bias=None, sample_bias=None, residual=None):
         _reject("conv3x3_nhwc: sample_bias must be [B, N]")
     TIMER.note_work("ed_conv3x3_nhwc", flops=2.0 * B * H * W * 9 * Cin * N,
                     nbytes=2.0 * (B * H * W * (Cin + N * (2 if residual is not None else 1)) + 9 * Cin * N))
-    _call("ed_conv3x3_nhwc", x.data_ptr(), w.data_ptr(), _opt(bias, x.dtype, "bias"), _opt(sample_bias, x.dtype, "sample_bias"),
-          None if residual is None else residual.data_ptr(), out.data_ptr(), _code(x, "x"), B, H, W, Cin, N, _stream_of(x))
+    BA = conv3x3_batch_split(B, H, W, N) if CONV_BATCH_SPLIT else None
+    for b0, nb in (((0, B),) if BA is None else ((0, BA), (BA, B - BA))):
+        # (the tail of a batch whose grid ends in a nearly empty round of 256-row tiles is launched on its own: the launcher runs it as 128-row tiles)
+        px, po = b0 * H * W * Cin * x.element_size(), b0 * H * W * N * x.element_size()
+        _call("ed_conv3x3_nhwc", x.data_ptr() + px, w.data_ptr(), _opt(bias, x.dtype, "bias"),
+              None if sample_bias is None else _dev(sample_bias, x.dtype, "sample_bias") + b0 * N * x.element_size(),
+              None if residual is None else residual.data_ptr() + po, out.data_ptr() + po, _code(x, "x"), nb, H, W, Cin, N, _stream_of(x))
     return out
+
+
+CONV_BATCH_SPLIT = True
+
+
+def conv3x3_batch_split(B, H, W, N):
+    """Samples of a batch ed_conv3x3_nhwc should run in a first launch (the rest in a second), or None for one launch.  One 128-KiB-LDS
+    workgroup per CU: a grid runs in rounds of 256 tiles, and the SDXL forwards of the default bench end some of them badly -- the 32 x 32
+    convolutions at 40 rows are 800 tiles: three full rounds and a fourth 12.5 % full.  Splitting the batch at a SAMPLE boundary (whole images:
+    the pixel geometry of either part is unchanged, and so is every output bit) lets the launcher run the short tail as 128-row tiles (0.72 of a
+    round): 3.72 rounds instead of 4.  Taken when the launcher's own cost model says the two launches finish at least 0.1 round sooner."""
+    HW = H * W
+    if HW % GEMM_BM or B < 2:
+        return None
+    ncb = -(-N // (2 * GEMM_BN))
+    tps = HW // GEMM_BM * ncb                      # 256-row tiles per sample
+    total = B * tps
+
+    def rounds(tiles):                             # the launcher's choice for a grid of `tiles` full tiles (csrc/gemm_kernels.hip, launch())
+        return min(-(-tiles // GEMM_CUS), -(-2 * tiles // GEMM_CUS) * GEMM_ROWS_TILE_COST)
+
+    full = total // GEMM_CUS
+    # measured (profiles/r6_s25_*): 800 tiles (3 full rounds + 32 tiles) +5.6...5.9 % per convolution, bit-identical, +0.23 % of the 40-row forward;
+    # 576 tiles (2 + 64) -4 % and 288 (1 + 32) +2.6 % alone, nothing in the forward: the model is only trusted from three full rounds on
+    if full < 3 or total % GEMM_CUS == 0:
+        return None
+    BA = full * GEMM_CUS // tps
+    if BA <= 0 or BA >= B:
+        return None
+    return BA if -(-BA * tps // GEMM_CUS) + rounds((B - BA) * tps) < rounds(total) - 0.1 else None
 
 
 def conv3x3_up2x_wins(B, H, W, Cin, N):

@@ -913,6 +913,32 @@ def test_upsample2d_module_takes_the_fused_kernel():
     assert got.shape == (6, 640, 64, 64) and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,N", [(40, 32, 32, 1280, 1280), (40, 32, 32, 640, 1280), (80, 32, 32, 320, 1280)])
+def test_convolution_batch_split_changes_no_bit(B, H, W, Cin, N, monkeypatch):
+    """ops.conv3x3_batch_split (round 6): a batch whose grid ends in a nearly empty round of 256-row tiles runs as two launches split at a sample
+    boundary (the tail as 128-row tiles) -- same pixel geometry, same sums in the same order: bit-identical to the single launch, with every
+    epilogue operand (bias, per-sample bias, residual) following the split."""
+    from elasticdiffusion_official_amd import ops
+    cl = torch.channels_last
+    BA = ops.conv3x3_batch_split(B, H, W, N)
+    assert BA is not None and 0 < BA < B
+    g = torch.Generator().manual_seed(B + H)
+    x = _asym((B, Cin, H, W), g).to(DEV, torch.float16).contiguous(memory_format=cl)
+    w = _asym((N, Cin, 3, 3), g, (9 * Cin) ** -0.5).to(DEV, torch.float16).contiguous(memory_format=cl)
+    b = _asym((N,), g).to(DEV, torch.float16)
+    sb = _asym((B, N), g).to(DEV, torch.float16)
+    r = _asym((B, N, H, W), g).to(DEV, torch.float16).contiguous(memory_format=cl)
+    for bias, sbias, res in ((b, None, None), (b, sb, None), (b, None, r), (b, sb, r)):
+        monkeypatch.setattr(ops, "CONV_BATCH_SPLIT", True)
+        ops.TIMER.start()
+        got = ops.conv3x3_nhwc(x, w, bias, sbias, res)
+        assert ops.TIMER.stop()["ed_conv3x3_nhwc"][0] == 2          # two launches
+        monkeypatch.setattr(ops, "CONV_BATCH_SPLIT", False)
+        assert torch.equal(got, ops.conv3x3_nhwc(x, w, bias, sbias, res))
+    assert ops.conv3x3_batch_split(20, 32, 32, 1280) is None and ops.conv3x3_batch_split(40, 128, 128, 320) is None
+    assert ops.conv3x3_batch_split(12, 64, 64, 640) is None          # 2 full rounds + 64 tiles: measured slower split, stays one launch
+
+
 def test_gemm_tile_height_is_chosen_by_round_count_and_both_heights_agree(monkeypatch, any_grid):
     """The launcher's own choice (no ED_GEMM_ROWS): 120 full tiles on 256 CUs (the batch-6 forward's 32 x 32 convolutions) run as 240
     128-row tiles.  Whatever it picks, the two tile heights compute the same sums in the same order per output element: bit-identical."""

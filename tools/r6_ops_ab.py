@@ -95,6 +95,20 @@ def main():
             flops = 4.0 * B * H * N * N * hd
             ab(f"flash_attention self B{B} H{H} N{N} hd{hd}", libs, lambda: ops.flash_attention(q, k, v, H), a.rounds,
                extra={"new_tflops": flops / 1e6})
+    if "convsplit" in only:      # ops.CONV_BATCH_SPLIT off / on in the SAME library: the batch tail as 128-row tiles
+        cl = torch.channels_last
+        for (B, Hh, W, Cin, N) in [(40, 32, 32, 1280, 1280), (40, 32, 32, 2560, 1280), (12, 64, 64, 640, 640), (6, 64, 64, 640, 640)]:
+            x = (torch.rand(B, Cin, Hh, W, generator=g) * 2 - 1).to(dev, dt).contiguous(memory_format=cl)
+            w = ((torch.rand(N, Cin, 3, 3, generator=g) * 2 - 1) / (9 * Cin) ** 0.5).to(dev, dt).contiguous(memory_format=cl)
+            b = (torch.rand(N, generator=g) * 2 - 1).to(dev, dt)
+
+            def run():
+                ops.CONV_BATCH_SPLIT = _hip._LIB is libs["new"]
+                try:
+                    return ops.conv3x3_nhwc(x, w, b)
+                finally:
+                    ops.CONV_BATCH_SPLIT = True
+            ab(f"conv3x3 batch split {B}x{Hh}x{W} {Cin}->{N}", libs, run, a.rounds, extra={"new_tflops": 2.0 * B * Hh * W * 9 * Cin * N / 1e6})
     if "gn" in only:
         cl = torch.channels_last
         for shape in [(40, 320, 128, 128), (40, 640, 64, 64), (40, 1280, 32, 32), (12, 320, 128, 128), (12, 1280, 32, 32), (20, 320, 128, 128), (20, 960, 128, 128), (20, 640, 64, 64), (20, 1920, 64, 64), (20, 1280, 32, 32), (20, 2560, 32, 32),

@@ -12,7 +12,15 @@ sys.path.insert(0, ROOT)
 import torch
 
 import elasticdiffusion_official_amd  # noqa: F401
-from elasticdiffusion_official_amd import models as M
+from elasticdiffusion_official_amd import models as M, ops
+
+
+def set_switch(name, value):
+    """`NAME` = a models switch, `ops.NAME` = an ops-level one (e.g. ops.CONV_BATCH_SPLIT)"""
+    if name.startswith("ops."):
+        setattr(ops, name[4:], value)
+    else:
+        setattr(M, name, value)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", default="40,12,20,6")
@@ -37,7 +45,7 @@ for batch in [int(v) for v in a.batches.split(",")]:
     arms = []
     for name, on in [("base", [])] + [(s, [s]) for s in SW] + [("all", SW)]:
         for s in SW:
-            setattr(M, s, s in on)
+            set_switch(s, s in on)
         with torch.no_grad():
             kv = unet.cross_attention_kv(e, None)
             fwd = lambda: unet(x, t, encoder_hidden_states=e, cross_kv=kv, **kw).sample   # noqa: E731
@@ -53,7 +61,7 @@ for batch in [int(v) for v in a.batches.split(",")]:
         torch.cuda.synchronize()
         arms.append({"arm": name, "graph": g, "out": out, "kv": kv, "ms": []})
     for s in SW:
-        setattr(M, s, True)
+        set_switch(s, True)
     for arm in arms:
         arm["graph"].replay()
     torch.cuda.synchronize()
