@@ -410,6 +410,39 @@ def test_round5_shape_policies_and_graph_keys():
     assert k0 != k1 and k0 == GraphedForward._key((20, 4, 128, 128), torch.float16, None)
 
 
+def test_round6_host_policies_and_cpu_fallbacks():
+    """Host-side decisions added in round 6, CPU only: the convolution batch split (a pure function of the grid), the shape gates of the
+    fused up-sampler / down-sampler / concatenation paths, and that on the CPU (the oracle's and the CPU baseline's copies of the modules)
+    every new path keeps plain-torch semantics."""
+    import torch
+    import torch.nn.functional as F
+    from elasticdiffusion_official_amd import models as M, ops
+    # 800 tiles (3 full rounds of 256 + 32): the last two samples run on their own; grids that end well, or under three rounds, stay one launch
+    assert ops.conv3x3_batch_split(40, 32, 32, 1280) == 38 and ops.conv3x3_batch_split(80, 32, 32, 1280) == 76
+    for shape in ((20, 32, 32, 1280), (12, 64, 64, 640), (6, 64, 64, 640), (40, 128, 128, 320), (40, 64, 64, 640), (1, 32, 32, 1280), (40, 8, 8, 1280)):
+        assert ops.conv3x3_batch_split(*shape) is None, shape
+    # the fused up-sampler takes full grids only (no 128-row instantiation); H, W = the OUTPUT size
+    assert ops.conv3x3_up2x_wins(20, 64, 64, 1280, 1280) and ops.conv3x3_up2x_wins(6, 128, 128, 640, 640)
+    assert not ops.conv3x3_up2x_wins(1, 64, 64, 1280, 1280) and not ops.conv3x3_up2x_wins(20, 63, 64, 1280, 1280)
+    assert ops.conv3x3_f32out_s2_ok(5, 256, 1024, 384, 128) and not ops.conv3x3_f32out_s2_ok(5, 255, 1024, 384, 128)
+    assert not ops.conv3x3_f32out_s2_ok(16, 256, 1024, 384, 128)                    # 3.2 GB operand: 32-bit offsets -> the model slices the batch
+    # CPU tensors never take a HIP path: ResnetBlock2D.forward_cat IS the block on the concatenation, Upsample2D / Downsample2D plain torch
+    torch.manual_seed(0)
+    blk = M.ResnetBlock2D(24 + 16, 32, 64, groups=8).eval()
+    x, skip, temb = torch.randn(2, 24, 6, 5), torch.randn(2, 16, 6, 5), torch.randn(2, 64)
+    with torch.no_grad():
+        assert torch.equal(blk.forward_cat(x, skip, temb), blk(torch.cat([x, skip], 1), temb))
+        down = M.Downsample2D(16, padding=0).eval()
+        y = torch.randn(2, 16, 8, 6)
+        assert torch.equal(down(y), F.conv2d(F.pad(y, (0, 1, 0, 1)), down.conv.weight, down.conv.bias, stride=2))
+    assert not ops.groupnorm_nhwc_cat_ok(x, skip, 8)                                  # CPU tensors
+    w1, w2 = M._split_shortcut(blk.conv_shortcut, 24)
+    assert torch.equal(torch.cat([w1, w2], 1), blk.conv_shortcut.weight.reshape(32, 40)) and w1.is_contiguous() and w2.is_contiguous()
+    # switches exist under the names the A/B tools and ED_DISABLE use; the two measured non-gains are off
+    assert M.FUSED_SKIP_CAT and M.FUSED_UPSAMPLE_CONV and M.FUSED_PROJ_OUT_ADD and M.VAE_SPLIT_DOWNSAMPLE
+    assert not M.HIP_DOWNSAMPLE_CONV and not M.FUSED_RESIDUAL_LINEAR
+
+
 def test_precision_attribution_tool_reproduces_its_headline_on_the_reduced_width_model():
     """tools/r5_precision_modes.py (CPU): rounding ONE class of values of the fp32 UNet to fp16 -- the reduced-width forward must show what
     profiles/r5_precision_attribution.json shows at full width: the classes are comparable (6-7e-4 each), attention's operands are
